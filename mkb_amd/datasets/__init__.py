@@ -1,0 +1,6 @@
+from .base import TestDataset, TestDatasetRelation, TrainDataset
+from .dataset import Dataset
+from .named import CountriesS1, Fb15k237, Umls, Wn18rr, Yago310
+
+__all__ = ["CountriesS1", "Dataset", "Fb15k237", "TestDataset", "TestDatasetRelation", "TrainDataset", "Umls",
+           "Wn18rr", "Yago310"]

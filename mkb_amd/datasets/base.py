@@ -1,0 +1,136 @@
+"""Host-side batch producers with the reference's item / batch formats.
+
+``TrainDataset`` (reference mkb/datasets/base.py:10-121) yields ``(LongTensor[3], weight[1], mode)``;
+``collate_fn`` -> ``{"sample": [B,3] int64, "weight": [B] f32, "mode": str}``.
+The subsampling weight is ``sqrt(1 / (count[(h,r)] + count[(t,-r-1)]))`` with counts starting at 3
+(base.py:101-121); here it is computed for all triples at once (vectorised, same fp32 ops).
+
+``TestDataset`` (base.py:163-251) yields, per test triple, the all-entity candidate list and the filter
+bias: candidate e keeps id e and bias 0 unless the corrupted triple is another true triple, in which case
+the id is replaced by the target and the bias is int(-1e5) = -100000.  ``TestDatasetRelation``
+(base.py:254-305) does the same over relations with bias -1.
+"""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+__all__ = ["TestDataset", "TestDatasetRelation", "TrainDataset"]
+
+
+def _as_array(triples):
+    return np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+
+
+def subsampling_weights(triples, start=3):
+    """fp32 weight per training triple (vectorised base.py:101-121)."""
+    a = _as_array(triples)
+    h, r, t = a[:, 0], a[:, 1], a[:, 2]
+    n_rel = int(r.max()) + 1 if len(a) else 1
+    n_ent = int(max(h.max(), t.max())) + 1 if len(a) else 1
+    k_hr = h * n_rel + r                      # (h, r)
+    k_tr = (n_ent + t) * n_rel + r            # (t, -r-1): disjoint key space
+    keys, inv, cnt = np.unique(np.concatenate([k_hr, k_tr]), return_inverse=True, return_counts=True)
+    c = cnt[inv]
+    total = (c[: len(a)] + start) + (c[len(a):] + start)
+    return torch.sqrt(1 / torch.from_numpy(total.astype(np.float32)))
+
+
+class TrainDataset(Dataset):
+    def __init__(self, triples, entities, relations, mode, pre_compute=True, seed=None):
+        if mode == "classification":
+            raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
+        self.entities = entities
+        self.relations = relations
+        self.mode = mode
+        self.n_entity = len(entities)
+        self.n_relation = len(relations)
+        self.pre_compute = pre_compute
+        self._rng = np.random.RandomState(seed)
+        self.triples = torch.from_numpy(_as_array(triples))
+        self.weights = subsampling_weights(triples)
+        self.len = len(self.triples)
+
+    def __len__(self):
+        return self.len
+
+    def __getitem__(self, idx):
+        return self.triples[idx], self.weights[idx: idx + 1], self.mode
+
+    @staticmethod
+    def collate_fn(data):
+        return {
+            "sample": torch.stack([d[0] for d in data], dim=0),
+            "weight": torch.cat([d[1] for d in data], dim=0),
+            "mode": data[0][2],
+        }
+
+
+class _TrueIndex:
+    """Sorted-key membership structure over the true triples (replaces the reference's python set)."""
+
+    def __init__(self, true_triples, n_entity, n_relation):
+        a = _as_array(true_triples)
+        self.n_entity, self.n_relation = n_entity, n_relation
+        self.key = np.unique((a[:, 0] * n_relation + a[:, 1]) * n_entity + a[:, 2])
+
+    def contains(self, h, r, t):
+        k = (np.asarray(h, dtype=np.int64) * self.n_relation + r) * self.n_entity + t
+        i = np.searchsorted(self.key, k)
+        i[i == len(self.key)] = 0
+        return self.key[i] == k
+
+
+class TestDataset(Dataset):
+    __test__ = False  # not a pytest class
+
+    def __init__(self, triples, true_triples, entities, relations, mode):
+        self.len = len(triples)
+        self.triples = triples
+        self.n_entity = len(entities)
+        self.n_relation = len(relations)
+        self.mode = mode
+        self.index = _TrueIndex(true_triples, self.n_entity, self.n_relation)
+
+    def __len__(self):
+        return self.len
+
+    def __getitem__(self, idx):
+        head, relation, tail = (int(v) for v in self.triples[idx])
+        cand = np.arange(self.n_entity, dtype=np.int64)
+        if self.mode == "head-batch":
+            true = self.index.contains(cand, relation, tail)
+            target = head
+        elif self.mode == "tail-batch":
+            true = self.index.contains(head, relation, cand)
+            target = tail
+        else:
+            raise ValueError(self.mode)
+        other = true & (cand != target)
+        negative_sample = torch.from_numpy(np.where(other, target, cand))
+        filter_bias = torch.from_numpy(np.where(other, np.float32(-100000.0), np.float32(0.0)).astype(np.float32))
+        return torch.LongTensor((head, relation, tail)), negative_sample, filter_bias, self.mode
+
+    @staticmethod
+    def collate_fn(data):
+        return {
+            "sample": torch.stack([d[0] for d in data], dim=0),
+            "negative_sample": torch.stack([d[1] for d in data], dim=0),
+            "filter_bias": torch.stack([d[2] for d in data], dim=0),
+            "mode": data[0][3],
+        }
+
+
+class TestDatasetRelation(TestDataset):
+    def __init__(self, triples, true_triples, entities, relations):
+        super().__init__(triples, true_triples, entities, relations, mode="relation-batch")
+
+    def __getitem__(self, idx):
+        head, relation, tail = (int(v) for v in self.triples[idx])
+        cand = np.arange(self.n_relation, dtype=np.int64)
+        true = self.index.contains(head, cand, tail)
+        rel = np.where(true, relation, cand)
+        bias = np.where(true, -1, 0).astype(np.int64)
+        bias[relation] = 0
+        negative_sample = torch.from_numpy(
+            np.stack([np.full(self.n_relation, head), rel, np.full(self.n_relation, tail)], axis=-1))
+        return torch.LongTensor((head, relation, tail)), negative_sample, torch.from_numpy(bias), self.mode
