@@ -1,0 +1,150 @@
+/* mkb_hip.h -- C ABI of libmkb_hip.so: the MI355X (gfx950) kernels behind mkb's triplet-scoring,
+ * self-adversarial loss and filtered negative-sampling hot path.
+ *
+ * The reference (raphaelsty/mkb) is pure Python on PyTorch and has NO FFI / plugin interface
+ * (SURVEY.md 8b); the boundary it offers is its public Python API.  Each entry point below names the
+ * reference call it stands in for (paths relative to /root/reference).  The host side
+ * (the mkb_amd Python package) mirrors that Python API and calls these symbols through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller (Python glue) owns and
+ *     allocates every buffer, nothing is allocated or freed across the ABI except opaque handles;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call is asynchronous with
+ *     respect to the host and ordered on that stream;
+ *   - return value: 0 = ok, <0 = mkb_status_t error; mkb_last_error() gives the message (thread local);
+ *   - floating point is IEEE fp32, indices are int64 (torch.LongTensor) unless stated;
+ *   - tables are row-major contiguous: ent [n_entity, entity_dim], rel [n_relation, relation_dim];
+ *     RotatE / ComplEx rows hold the real half first, then the imaginary half (models/rotate.py:76-77).
+ */
+#ifndef MKB_HIP_H
+#define MKB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKB_ABI_VERSION 1
+
+typedef enum {
+    MKB_OK = 0,
+    MKB_ERR_INVALID = -1,   /* bad argument (shape, enum, null pointer, misalignment)            */
+    MKB_ERR_HIP = -2,       /* a HIP runtime call failed                                          */
+    MKB_ERR_KEY = -3,       /* sampler: (r,t) / (h,r) not in the training triples (ref: KeyError) */
+    MKB_ERR_EMPTY = -4,     /* sampler: a row's filter removed the whole pool (ref: infinite loop)*/
+    MKB_ERR_UNSUPPORTED = -5
+} mkb_status_t;
+
+/* models/transe.py:65, rotate.py:69, complex.py:65, distmult.py:63, protate.py:74 */
+typedef enum { MKB_TRANSE = 0, MKB_ROTATE = 1, MKB_COMPLEX = 2, MKB_DISTMULT = 3, MKB_PROTATE = 4 } mkb_model_t;
+
+/* models/base.py:153-164: any mode string other than the two below selects the default batch */
+typedef enum { MKB_MODE_DEFAULT = 0, MKB_MODE_HEAD = 1, MKB_MODE_TAIL = 2 } mkb_mode_t;
+
+/* Parameter set of one model == the nn.Parameters of models/base.py:66-100 (+ modulus, protate.py:72). */
+typedef struct {
+    int32_t model;            /* mkb_model_t */
+    int32_t hidden_dim;
+    int64_t n_entity, n_relation;
+    int64_t entity_dim, relation_dim;
+    const float *ent;         /* [n_entity, entity_dim]                       */
+    const float *rel;         /* [n_relation, relation_dim]                   */
+    const float *modulus;     /* [1] device scalar (pRotatE), may be null     */
+    float gamma;              /* gamma.item()                                 */
+    float phase_div;          /* fp32(embedding_range.item() / pi): rotate.py:79, protate.py:78-80 */
+} mkb_tables_t;
+
+/* Dense gradient buffers == .grad of the same parameters (accumulated into, never zeroed here). */
+typedef struct {
+    float *g_ent;             /* [n_entity, entity_dim]   */
+    float *g_rel;             /* [n_relation, relation_dim] */
+    float *g_modulus;         /* [1] (pRotatE) or null    */
+} mkb_grads_t;
+
+int mkb_abi_version(void);
+const char *mkb_last_error(void);
+
+/* ---- general scoring (arbitrary candidate ids) ------------------------------------------------------
+ * mkb_score_fwd == model.forward(sample, negative_sample, mode)          (forward of each file under models/)
+ *   sample [B,3]; cand [B,K] candidate entity ids (head-batch: heads, tail-batch: tails) or null with
+ *   K = 1 for MKB_MODE_DEFAULT (candidate = the true tail, base.py:166-175); score [B,K] out.
+ * mkb_score_bwd == autograd of the same call: accumulates d loss/d tables given dscore [B,K]
+ *   (index_select backward = dense index_add_).
+ */
+int mkb_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *cand, int64_t B, int64_t K,
+                  int mode, float *score, void *stream);
+int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const int64_t *cand,
+                  int64_t B, int64_t K, int mode, const float *dscore, void *stream);
+
+/* ---- self-adversarial loss ---------------------------------------------------------------------------
+ * mkb_adversarial == losses.Adversarial(alpha)(positive_score, negative_score, weight) AND its gradient
+ * (losses/adversarial.py:21-30): loss[1], dpos[B], dneg[B,K] out.  cnt (uint16 [B,K]) is an optional
+ * per-column multiplicity (null = all ones) used by the pooled path, where a column is a pool position.
+ * scratch: B+1 floats of caller-owned device memory (W and the per-row partial sums; the reduction is a
+ * fixed tree, so the loss is bit-reproducible run to run).
+ */
+int mkb_adversarial(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B,
+                    int64_t K, float alpha, float *loss, float *dpos, float *dneg, float *scratch, void *stream);
+
+/* ---- negative sampler --------------------------------------------------------------------------------
+ * mkb_sampler_create == sampling.NegativeSampling.__init__ (negative_sampling.py:133-151): takes the two
+ *   filter dictionaries of positive_triples() (negative_sampling.py:7-28) as CSR on the HOST:
+ *   keys sorted ascending (head filter: r*n_entity+t -> heads; tail filter: h*n_relation+r -> tails),
+ *   offsets [nk+1], values sorted ascending within each set.  Copies them to the device.
+ * mkb_sampler_generate == NegativeSampling.generate(sample, mode) (negative_sampling.py:158-201), bit-exact
+ *   with numpy's legacy MT19937 randint + np.in1d(assume_unique=True, invert=True) of numpy >= 1.24:
+ *   neg [B,K] int64 out; optional outs for the pooled scoring path: pool [2K] int64 (the shared candidate
+ *   draw), pos [B,K] int32 (neg[i,j] == pool[pos[i,j]]), cnt [B,2K] uint16 (multiplicity of each pool
+ *   position in row i).  status [1] int32 device out: 0 / MKB_ERR_KEY / MKB_ERR_EMPTY (first failing row
+ *   in status[1]); checked lazily by the host with mkb_sampler_status.
+ */
+typedef struct mkb_sampler mkb_sampler_t;
+int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t n_relation, int64_t K, uint32_t seed,
+                       const int64_t *head_keys_host, int64_t n_head_keys, const int64_t *head_offsets_host,
+                       const int64_t *head_values_host, const int64_t *tail_keys_host, int64_t n_tail_keys,
+                       const int64_t *tail_offsets_host, const int64_t *tail_values_host, void *stream);
+int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int64_t B, int mode, int64_t *neg,
+                         int64_t *pool, int32_t *pos, uint16_t *cnt, void *stream);
+int mkb_sampler_status(mkb_sampler_t *s, void *stream); /* synchronises `stream`; returns 0 or the error */
+int mkb_sampler_get_state(mkb_sampler_t *s, uint32_t *key624_host, int32_t *pos_host, void *stream);
+int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_host, int32_t pos, void *stream);
+void mkb_sampler_destroy(mkb_sampler_t *s);
+
+/* ---- pooled training step ----------------------------------------------------------------------------
+ * == compose/pipeline.py:211-236 for one batch whose negatives come from ONE shared pool
+ * (negative_sampling.py:166): positive forward (mode None), negative forward (mode), Adversarial,
+ * backward into the dense gradient buffers.  Uses pool/cnt from mkb_sampler_generate.
+ *   ws: workspace of mkb_pool_step_workspace_bytes() bytes; pos_score [B] out, pool_score [B,2K] out
+ *   (score of row i against pool position p, valid where cnt>0), loss [1] out.
+ */
+int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K);
+int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                  const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                  float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
+/* forward only (pooled model.forward): pool_score [B,2K] */
+int mkb_pool_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
+                       int64_t B, int64_t K, int mode, float *pool_score, void *ws, void *stream);
+
+/* ---- dense Adam --------------------------------------------------------------------------------------
+ * == torch.optim.Adam(lr, betas, eps).step() + zero_grad() for one parameter tensor as the README loop
+ * uses it (README.md:123-126, pipeline.py:238-240): every element moves every step.  step is 1-based.
+ * zero_grad != 0 also clears g (fused optimizer.zero_grad()).
+ */
+int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, float lr,
+                  float beta1, float beta2, float eps, int zero_grad, void *stream);
+
+/* ---- filtered ranking --------------------------------------------------------------------------------
+ * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the
+ * candidate list and filter bias of datasets.base.TestDataset (datasets/base.py:196-241): for each test triple
+ * the rank of the target among all n_entity candidates, other true triples biased by -100000.
+ *   true_keys: sorted int64 keys ((h*n_relation + r)*n_entity + t) of all true triples (device);
+ *   rank [B] int64 out (1-based).
+ */
+int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+             int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKB_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of ``libmkb_hip.so`` (C ABI: ``include/mkb_hip.h``).
+
+The library is the ONLY compute backend of ``mkb_amd``: if it cannot be loaded, or a tensor is not on a
+ROCm device, the call raises -- there is no CPU fallback (the CPU restatement under ``oracle/`` is test
+infrastructure and is never imported from here).
+"""
+import ctypes
+import pathlib
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint16, c_uint32, c_void_p
+
+import torch
+
+_LIB_PATH = pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"
+ABI_VERSION = 1
+
+MODEL_IDS = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}
+MODE_DEFAULT, MODE_HEAD, MODE_TAIL = 0, 1, 2
+ERR_KEY, ERR_EMPTY = -3, -4
+
+
+def mode_id(mode):
+    """models/base.py:153-164: only the two batch strings select a candidate side."""
+    return MODE_HEAD if mode == "head-batch" else MODE_TAIL if mode == "tail-batch" else MODE_DEFAULT
+
+
+class Tables(Structure):
+    _fields_ = [("model", c_int32), ("hidden_dim", c_int32), ("n_entity", c_int64), ("n_relation", c_int64),
+                ("entity_dim", c_int64), ("relation_dim", c_int64), ("ent", c_void_p), ("rel", c_void_p),
+                ("modulus", c_void_p), ("gamma", c_float), ("phase_div", c_float)]
+
+
+class Grads(Structure):
+    _fields_ = [("g_ent", c_void_p), ("g_rel", c_void_p), ("g_modulus", c_void_p)]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    "mkb_abi_version": (c_int, []),
+    "mkb_last_error": (c_char_p, []),
+    "mkb_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mkb_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                              c_void_p]),
+    "mkb_adversarial": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "mkb_sampler_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_uint32, c_void_p, c_int64, c_void_p,
+                                   c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mkb_sampler_generate": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
+    "mkb_sampler_status": (c_int, [c_void_p, c_void_p]),
+    "mkb_sampler_get_state": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
+    "mkb_sampler_set_state": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
+    "mkb_sampler_destroy": (None, [c_void_p]),
+    "mkb_pool_step_workspace_bytes": (c_int64, [POINTER(Tables), c_int64, c_int64]),
+    "mkb_pool_step": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                              c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mkb_pool_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
+    "mkb_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
+                              c_float, c_int, c_void_p]),
+    "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                         c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises HipLibraryError if the .so is missing."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise HipLibraryError(
+                f"{_LIB_PATH} not found: build it with `python -m mkb_amd.csrc.build` "
+                "(mkb_amd has no CPU fallback; the HIP library is the only compute path)")
+        handle = ctypes.CDLL(str(_LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        if handle.mkb_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f"ABI version mismatch: library {handle.mkb_abi_version()}, binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mkb_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what} failed (status {rc}): {msg}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mkb_amd computes on ROCm devices only (no CPU fallback): move the model and its inputs to 'cuda'. "
+                f"Got a tensor on {t.device}.")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def contiguous(t, dtype):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,116 @@
+// mkb_adversarial: self-adversarial negative-sampling loss, forward AND gradient seed in one pass.
+//
+// Replaces losses.Adversarial.__call__ (losses/adversarial.py:21-30) and its autograd:
+//   ps_i = logsigmoid(pos_i); p_ij = softmax_j(alpha * neg_ij) (detached); ns_i = sum_j p_ij logsigmoid(-neg_ij)
+//   loss = ( -sum_i w_i ps_i / W  -  sum_i w_i ns_i / W ) / 2,   W = sum_i w_i
+//   d loss/d pos_i = -(w_i / 2W) sigmoid(-pos_i);   d loss/d neg_ij = +(w_i / 2W) p_ij sigmoid(neg_ij)
+// Optional column multiplicities cnt[i,j] (pooled path: column = pool position used cnt times by row i):
+//   softmax and the sums run over columns weighted by cnt; dneg_ij is the summed gradient of its copies.
+//
+// Kernel 0 (single workgroup): W by a fixed reduction tree.  Kernel 1 (one wave per row, 4 rows per
+//   workgroup): row max / partition sum / weighted log-sigmoid sum with wave64 shuffle reductions, writes
+//   dpos, dneg and the per-row partial.  Kernel 2 (single workgroup): fixed-tree sum of the partials.
+//   No float atomics: the loss is bit-reproducible run to run.
+#include "common.h"
+#include "model_math.h"
+
+namespace mkb {
+
+__device__ __forceinline__ float log_sigmoid(float z) {  // min(z,0) - log1p(exp(-|z|)), as ATen does
+    return fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
+}
+__device__ __forceinline__ float sigmoid(float z) { return 1.f / (1.f + expf(-z)); }
+
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// scal[0] = W
+__global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict__ w, int B, float *__restrict__ scal) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) scal[0] = acc;
+}
+
+// one wave per row; rowpart[i] = w_i * (ps_i + ns_i)
+__global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
+                                                               const float *__restrict__ w, const uint16_t *__restrict__ cnt,
+                                                               int B, int K, float alpha, const float *__restrict__ scal,
+                                                               float *__restrict__ dpos, float *__restrict__ dneg,
+                                                               float *__restrict__ rowpart) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const float *nrow = neg + (int64_t)i * K;
+    const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
+    float m = -INFINITY;
+    for (int j = lane; j < K; j += 64)
+        if (!crow || crow[j]) m = fmaxf(m, alpha * nrow[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float z = 0.f, s = 0.f;
+    for (int j = lane; j < K; j += 64) {
+        const float c = crow ? (float)crow[j] : 1.f;
+        if (c > 0.f) {
+            const float v = nrow[j];
+            const float e = c * expf(alpha * v - m);
+            z += e;
+            s += e * log_sigmoid(-v);
+        }
+    }
+    z = wave_sum(z);
+    s = wave_sum(s);
+    const float W = scal[0];
+    const float wi = w[i];
+    const float coef = 0.5f * wi / W;
+    const float invz = 1.f / z;
+    for (int j = lane; j < K; j += 64) {
+        const float c = crow ? (float)crow[j] : 1.f;
+        float g = 0.f;
+        if (c > 0.f) {
+            const float v = nrow[j];
+            g = coef * (c * expf(alpha * v - m) * invz) * sigmoid(v);
+        }
+        dneg[(int64_t)i * K + j] = g;
+    }
+    if (lane == 0) {
+        const float p = pos[i];
+        dpos[i] = -coef * sigmoid(-p);
+        rowpart[i] = wi * (log_sigmoid(p) + s * invz);
+    }
+}
+
+__global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__restrict__ rowpart, int B,
+                                                                 const float *__restrict__ scal, float *__restrict__ loss) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += rowpart[i];
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) loss[0] = -0.5f * acc / scal[0];
+}
+
+}  // namespace mkb
+
+using namespace mkb;
+
+extern "C" int mkb_adversarial(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B,
+                               int64_t K, float alpha, float *loss, float *dpos, float *dneg, float *scratch,
+                               void *stream) {
+    MKB_REQUIRE(pos && neg && weight && loss && dpos && dneg && scratch, "null pointer");
+    MKB_REQUIRE(B > 0 && K > 0 && B <= INT32_MAX && K <= INT32_MAX, "bad B / K");
+    hipStream_t st = (hipStream_t)stream;
+    float *scal = scratch, *rowpart = scratch + 1;
+    hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
+    hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
+                       (int)B, (int)K, alpha, scal, dpos, dneg, rowpart);
+    hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B, scal, loss);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}

@@ -1,0 +1,169 @@
+// Per-element math of the five KGE score functions in the query / candidate decomposition
+// (see oracle/closed.py for the float64 statement that pins it, and DESIGN.md section 3).
+//
+//   score(i, x) = c0 - m * sum_k f(q_i[k], x[k])        q_i = query built from the two fixed operands
+//
+// Reference formulas: models/transe.py:65-76, rotate.py:69-99, complex.py:65-85, distmult.py:63-75,
+// protate.py:74-93 (paths relative to /root/reference).  fp32 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mkb_hip.h"
+
+namespace mkb {
+
+// A "unit" is the smallest group of floats the pair function couples: one float for the real models,
+// one complex number (re at k, im at d+k) for RotatE.  ComplEx's pair function is a plain dot product
+// over the 2d floats of the query, so it only needs complex units when BUILDING the query.
+template <int MODEL> struct ModelTraits;
+template <> struct ModelTraits<MKB_TRANSE>   { static constexpr bool cplx_query = false, cplx_pair = false, uses_gamma = true;  };
+template <> struct ModelTraits<MKB_DISTMULT> { static constexpr bool cplx_query = false, cplx_pair = false, uses_gamma = false; };
+template <> struct ModelTraits<MKB_PROTATE>  { static constexpr bool cplx_query = false, cplx_pair = false, uses_gamma = true;  };
+template <> struct ModelTraits<MKB_COMPLEX>  { static constexpr bool cplx_query = true,  cplx_pair = false, uses_gamma = false; };
+template <> struct ModelTraits<MKB_ROTATE>   { static constexpr bool cplx_query = true,  cplx_pair = true,  uses_gamma = true;  };
+
+struct Cplx { float re, im; };
+
+// ---------------------------------------------------------------- query build (real models)
+// a, b = the two fixed operands: tail-style (h, r), head-style (r, t).
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ float build_q_real(float a, float b, float kd) {
+    if constexpr (MODEL == MKB_TRANSE) return HEAD ? (a - b) : (a + b);            // r - t | h + r
+    if constexpr (MODEL == MKB_DISTMULT) return a * b;                              // r * t | h * r
+    if constexpr (MODEL == MKB_PROTATE) return HEAD ? (a / kd - b / kd) : (a / kd + b / kd);
+    return 0.f;
+}
+
+// ---------------------------------------------------------------- query build (complex models)
+// tail-style: e = h (entity), r = relation.  head-style: e = t.
+// RotatE: r_re holds the phase source (relation value), r_im unused.
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ Cplx build_q_cplx(Cplx e, Cplx r, float kd) {
+    float c, s;
+    if constexpr (MODEL == MKB_ROTATE) {
+        const float phase = r.re / kd;
+        c = cosf(phase);
+        s = sinf(phase);
+    } else {
+        c = r.re;
+        s = r.im;
+    }
+    Cplx q;
+    if constexpr (HEAD) {  // conj(rot) (x) t     rotate.py:84-85, complex.py:74-75
+        q.re = c * e.re + s * e.im;
+        q.im = c * e.im - s * e.re;
+    } else {               // h (x) rot           rotate.py:89-90, complex.py:79-80
+        q.re = e.re * c - e.im * s;
+        q.im = e.re * s + e.im * c;
+    }
+    return q;
+}
+
+// ---------------------------------------------------------------- pair terms (forward)
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ float pair_term_real(float q, float x, float kd) {
+    if constexpr (MODEL == MKB_TRANSE) return fabsf(HEAD ? (x + q) : (q - x));
+    if constexpr (MODEL == MKB_DISTMULT || MODEL == MKB_COMPLEX) return q * x;
+    if constexpr (MODEL == MKB_PROTATE) return fabsf(sinf(HEAD ? (x / kd + q) : (q - x / kd)));
+    return 0.f;
+}
+
+__device__ __forceinline__ float pair_term_cmod(Cplx q, Cplx x) {  // rotate.py:86-87 / 91-96
+    const float a = q.re - x.re, b = q.im - x.im;
+    return sqrtf(a * a + b * b);
+}
+
+template <int MODEL>
+__device__ __forceinline__ float finish_score(float sum, float gamma, float modulus) {
+    if constexpr (MODEL == MKB_TRANSE || MODEL == MKB_ROTATE) return gamma - sum;
+    if constexpr (MODEL == MKB_PROTATE) return gamma - sum * modulus;
+    return sum;
+}
+
+// ---------------------------------------------------------------- pair terms (backward)
+// Given upstream g = dL/dscore, returns the contribution to dq and to dx.
+// extra accumulates sum_k |sin z| for pRotatE's modulus gradient.
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ void pair_bwd_real(float q, float x, float g, float kd, float modulus, float &dq,
+                                              float &dx, float &extra) {
+    if constexpr (MODEL == MKB_TRANSE) {
+        const float z = HEAD ? (x + q) : (q - x);
+        const float sg = (z > 0.f) ? 1.f : ((z < 0.f) ? -1.f : 0.f);
+        dq = -g * sg;
+        dx = HEAD ? (-g * sg) : (g * sg);
+    } else if constexpr (MODEL == MKB_DISTMULT || MODEL == MKB_COMPLEX) {
+        dq = g * x;
+        dx = g * q;
+    } else if constexpr (MODEL == MKB_PROTATE) {
+        const float z = HEAD ? (x / kd + q) : (q - x / kd);
+        const float sz = sinf(z);
+        const float sg = (sz > 0.f) ? 1.f : ((sz < 0.f) ? -1.f : 0.f);
+        const float c = cosf(z) * sg * modulus;
+        dq = -g * c;
+        dx = (HEAD ? (-g * c) : (g * c)) / kd;
+        extra += fabsf(sz);
+    }
+}
+
+__device__ __forceinline__ void pair_bwd_cmod(Cplx q, Cplx x, float g, Cplx &dq, Cplx &dx) {
+    const float a = q.re - x.re, b = q.im - x.im;
+    const float n2 = a * a + b * b;
+    const float w = (n2 > 0.f) ? g * rsqrtf(n2) : 0.f;  // torch norm backward: 0 at the origin
+    dx.re = w * a;
+    dx.im = w * b;
+    dq.re = -dx.re;
+    dq.im = -dx.im;
+}
+
+// ---------------------------------------------------------------- query backward
+// Chain dq through build_q into the two fixed operands (a, b as in build_q_*).
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ void query_bwd_real(float a, float b, float dq, float kd, float &da, float &db) {
+    if constexpr (MODEL == MKB_TRANSE) { da = dq; db = HEAD ? -dq : dq; }
+    if constexpr (MODEL == MKB_DISTMULT) { da = dq * b; db = dq * a; }
+    if constexpr (MODEL == MKB_PROTATE) { da = dq / kd; db = (HEAD ? -dq : dq) / kd; }
+}
+
+// e = entity operand (h tail-style, t head-style), r = relation operand.  Returns de (complex) and
+// dr: ComplEx -> complex gradient of r; RotatE -> dr.re = gradient of the phase source, dr.im = 0.
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ void query_bwd_cplx(Cplx e, Cplx r, Cplx dq, float kd, Cplx &de, Cplx &dr) {
+    float c, s;
+    if constexpr (MODEL == MKB_ROTATE) {
+        const float phase = r.re / kd;
+        c = cosf(phase);
+        s = sinf(phase);
+    } else {
+        c = r.re;
+        s = r.im;
+    }
+    float dc, ds;
+    if constexpr (HEAD) {  // q.re = c e.re + s e.im ; q.im = c e.im - s e.re
+        de.re = dq.re * c - dq.im * s;
+        de.im = dq.re * s + dq.im * c;
+        dc = dq.re * e.re + dq.im * e.im;
+        ds = dq.re * e.im - dq.im * e.re;
+    } else {               // q.re = e.re c - e.im s ; q.im = e.re s + e.im c
+        de.re = dq.re * c + dq.im * s;
+        de.im = -dq.re * s + dq.im * c;
+        dc = dq.re * e.re + dq.im * e.im;
+        ds = -dq.re * e.im + dq.im * e.re;
+    }
+    if constexpr (MODEL == MKB_ROTATE) {
+        dr.re = (ds * c - dc * s) / kd;  // d/dphase then / kd
+        dr.im = 0.f;
+    } else {
+        dr.re = dc;
+        dr.im = ds;
+    }
+}
+
+// ---------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace mkb

@@ -1,0 +1,234 @@
+// General (arbitrary candidate ids) scoring kernels: mkb_score_fwd / mkb_score_bwd.
+//
+// Replaces, for one call of model.forward(sample, negative_sample, mode) and its autograd:
+//   BaseModel.batch gather (models/base.py:153-207) + <Model>.forward math (models/*.py) and the
+//   index_select backward (dense index_add_), SURVEY.md a3-a8, a13.
+//
+// Forward  : one workgroup per batch row.  The row's query vector q_i (built from the two fixed
+//            operands) is staged in LDS once and shared by all K candidates; each of the 4 waves streams
+//            whole candidate rows with coalesced loads and finishes with a wave64 shuffle reduction.
+// Backward : one workgroup per batch row, each lane OWNS units k (no cross-lane reduction at all):
+//            dq accumulates in registers over the K candidates, candidate-row gradients go out as
+//            coalesced fp32 atomics, then dq is chained into the fixed operands' rows.
+// The [B,K,D] intermediates of the reference are never materialised.
+#include "common.h"
+#include "model_math.h"
+
+namespace mkb {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+struct TablesDev {
+    const float *ent, *rel, *modulus;
+    int64_t De, Dr;
+    int d;
+    float gamma, kd;
+};
+
+static TablesDev to_dev(const mkb_tables_t *tb) {
+    TablesDev t;
+    t.ent = tb->ent; t.rel = tb->rel; t.modulus = tb->modulus;
+    t.De = tb->entity_dim; t.Dr = tb->relation_dim; t.d = tb->hidden_dim;
+    t.gamma = tb->gamma; t.kd = tb->phase_div;
+    return t;
+}
+
+// Build q for unit u of row (h, r, t).  Real models: one float.  Complex-query models: (re, im).
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ void build_unit(const TablesDev &T, const float *eh, const float *er, const float *et,
+                                           int u, float &q0, float &q1) {
+    if constexpr (ModelTraits<MODEL>::cplx_query) {
+        const float *e = HEAD ? et : eh;
+        Cplx ec{e[u], e[T.d + u]};
+        Cplx rc{er[u], MODEL == MKB_COMPLEX ? er[T.d + u] : 0.f};
+        Cplx q = build_q_cplx<MODEL, HEAD>(ec, rc, T.kd);
+        q0 = q.re; q1 = q.im;
+    } else {
+        const float a = HEAD ? er[u] : eh[u];
+        const float b = HEAD ? et[u] : er[u];
+        q0 = build_q_real<MODEL, HEAD>(a, b, T.kd);
+        q1 = 0.f;
+    }
+}
+
+template <int MODEL, bool HEAD>
+__global__ __launch_bounds__(kBlock) void score_fwd_kernel(TablesDev T, const int64_t *__restrict__ sample,
+                                                           const int64_t *__restrict__ cand, int K,
+                                                           float *__restrict__ score) {
+    extern __shared__ __attribute__((aligned(16))) float q_lds[];
+    const int i = blockIdx.x;
+    const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
+    const float *eh = T.ent + h * T.De, *er = T.rel + r * T.Dr, *et = T.ent + t * T.De;
+    const int U = ModelTraits<MODEL>::cplx_query ? T.d : (int)T.De;
+    for (int u = threadIdx.x; u < U; u += kBlock) {
+        float q0, q1;
+        build_unit<MODEL, HEAD>(T, eh, er, et, u, q0, q1);
+        q_lds[u] = q0;
+        if constexpr (ModelTraits<MODEL>::cplx_query) q_lds[T.d + u] = q1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float modulus = (MODEL == MKB_PROTATE) ? T.modulus[0] : 0.f;
+    for (int j = wave; j < K; j += kWaves) {
+        const int64_t c = cand ? cand[(int64_t)i * K + j] : t;
+        const float *x = T.ent + c * T.De;
+        float acc = 0.f;
+        if constexpr (ModelTraits<MODEL>::cplx_pair) {
+            for (int k = lane; k < T.d; k += 64)
+                acc += pair_term_cmod(Cplx{q_lds[k], q_lds[T.d + k]}, Cplx{x[k], x[T.d + k]});
+        } else {
+            for (int k = lane; k < (int)T.De; k += 64) acc += pair_term_real<MODEL, HEAD>(q_lds[k], x[k], T.kd);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) score[(int64_t)i * K + j] = finish_score<MODEL>(acc, T.gamma, modulus);
+    }
+}
+
+template <int MODEL, bool HEAD>
+__global__ __launch_bounds__(kBlock) void score_bwd_kernel(TablesDev T, mkb_grads_t G,
+                                                           const int64_t *__restrict__ sample,
+                                                           const int64_t *__restrict__ cand, int K,
+                                                           const float *__restrict__ dscore) {
+    __shared__ float red[kWaves];
+    const int i = blockIdx.x;
+    const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
+    const float *eh = T.ent + h * T.De, *er = T.rel + r * T.Dr, *et = T.ent + t * T.De;
+    float *g_e = G.g_ent + (HEAD ? t : h) * T.De;  // fixed entity operand of the query
+    float *g_r = G.g_rel + r * T.Dr;
+    const int U = ModelTraits<MODEL>::cplx_query ? T.d : (int)T.De;
+    const float modulus = (MODEL == MKB_PROTATE) ? T.modulus[0] : 0.f;
+    float extra = 0.f;
+    for (int u = threadIdx.x; u < U; u += kBlock) {
+        float q0, q1;
+        build_unit<MODEL, HEAD>(T, eh, er, et, u, q0, q1);
+        float dq0 = 0.f, dq1 = 0.f;
+        for (int j = 0; j < K; ++j) {
+            const float g = dscore[(int64_t)i * K + j];
+            const int64_t c = cand ? cand[(int64_t)i * K + j] : t;
+            const float *x = T.ent + c * T.De;
+            float *gx = G.g_ent + c * T.De;
+            if constexpr (ModelTraits<MODEL>::cplx_pair) {
+                Cplx dq, dx;
+                pair_bwd_cmod(Cplx{q0, q1}, Cplx{x[u], x[T.d + u]}, g, dq, dx);
+                dq0 += dq.re; dq1 += dq.im;
+                atomicAdd(gx + u, dx.re);
+                atomicAdd(gx + T.d + u, dx.im);
+            } else if constexpr (ModelTraits<MODEL>::cplx_query) {  // ComplEx: dot over both halves
+                float a, b, e0 = 0.f;
+                pair_bwd_real<MODEL, HEAD>(q0, x[u], g, T.kd, modulus, a, b, e0);
+                dq0 += a; atomicAdd(gx + u, b);
+                pair_bwd_real<MODEL, HEAD>(q1, x[T.d + u], g, T.kd, modulus, a, b, e0);
+                dq1 += a; atomicAdd(gx + T.d + u, b);
+            } else {
+                float a, b, e0 = 0.f;
+                pair_bwd_real<MODEL, HEAD>(q0, x[u], g, T.kd, modulus, a, b, e0);
+                dq0 += a; atomicAdd(gx + u, b);
+                extra += g * e0;
+            }
+        }
+        // chain dq into the fixed operands (duplicates across rows add: atomics)
+        if constexpr (ModelTraits<MODEL>::cplx_query) {
+            const float *e = HEAD ? et : eh;
+            Cplx de, dr;
+            query_bwd_cplx<MODEL, HEAD>(Cplx{e[u], e[T.d + u]}, Cplx{er[u], MODEL == MKB_COMPLEX ? er[T.d + u] : 0.f},
+                                        Cplx{dq0, dq1}, T.kd, de, dr);
+            atomicAdd(g_e + u, de.re);
+            atomicAdd(g_e + T.d + u, de.im);
+            atomicAdd(g_r + u, dr.re);
+            if constexpr (MODEL == MKB_COMPLEX) atomicAdd(g_r + T.d + u, dr.im);
+        } else {
+            const float a = HEAD ? er[u] : eh[u], b = HEAD ? et[u] : er[u];
+            float da, db;
+            query_bwd_real<MODEL, HEAD>(a, b, dq0, T.kd, da, db);
+            // tail-style: a = h, b = r ; head-style: a = r, b = t
+            atomicAdd((HEAD ? g_r : g_e) + u, da);
+            atomicAdd((HEAD ? g_e : g_r) + u, db);
+        }
+    }
+    if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
+        extra = wave_sum(extra);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = extra;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int w = 0; w < kWaves; ++w) s += red[w];
+            atomicAdd(G.g_modulus, -s);
+        }
+    }
+}
+
+template <int MODEL>
+static int launch_fwd(const TablesDev &T, const int64_t *sample, const int64_t *cand, int64_t B, int K, bool head,
+                      float *score, hipStream_t st) {
+    const size_t lds = (size_t)T.De * sizeof(float);
+    if (head)
+        hipLaunchKernelGGL((score_fwd_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), lds, st, T, sample, cand, K, score);
+    else
+        hipLaunchKernelGGL((score_fwd_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), lds, st, T, sample, cand, K, score);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+template <int MODEL>
+static int launch_bwd(const TablesDev &T, const mkb_grads_t &G, const int64_t *sample, const int64_t *cand, int64_t B,
+                      int K, bool head, const float *dscore, hipStream_t st) {
+    if (head)
+        hipLaunchKernelGGL((score_bwd_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
+    else
+        hipLaunchKernelGGL((score_bwd_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+static int check_call(const mkb_tables_t *tb, const int64_t *sample, const int64_t *cand, int64_t B, int64_t K, int mode) {
+    if (int rc = validate_tables(tb)) return rc;
+    MKB_REQUIRE(sample != nullptr && B >= 0 && K >= 1, "bad sample / B / K");
+    MKB_REQUIRE(mode >= MKB_MODE_DEFAULT && mode <= MKB_MODE_TAIL, "bad mode %d", mode);
+    MKB_REQUIRE(mode == MKB_MODE_DEFAULT ? (cand == nullptr && K == 1) : (cand != nullptr),
+                "default mode takes no candidates (K=1); head/tail-batch need them");
+    MKB_REQUIRE(tb->entity_dim * 4 <= 64 * 1024, "entity_dim too large for the LDS-staged query");
+    MKB_REQUIRE(K <= INT32_MAX && B <= INT32_MAX, "B / K too large");
+    return MKB_OK;
+}
+
+}  // namespace mkb
+
+using namespace mkb;
+
+extern "C" int mkb_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *cand, int64_t B, int64_t K,
+                             int mode, float *score, void *stream) {
+    if (int rc = check_call(tb, sample, cand, B, K, mode)) return rc;
+    MKB_REQUIRE(score != nullptr, "score is null");
+    if (B == 0) return MKB_OK;
+    const TablesDev T = to_dev(tb);
+    hipStream_t st = (hipStream_t)stream;
+    const bool head = mode_is_head(mode);
+    switch (tb->model) {
+        case MKB_TRANSE: return launch_fwd<MKB_TRANSE>(T, sample, cand, B, (int)K, head, score, st);
+        case MKB_ROTATE: return launch_fwd<MKB_ROTATE>(T, sample, cand, B, (int)K, head, score, st);
+        case MKB_COMPLEX: return launch_fwd<MKB_COMPLEX>(T, sample, cand, B, (int)K, head, score, st);
+        case MKB_DISTMULT: return launch_fwd<MKB_DISTMULT>(T, sample, cand, B, (int)K, head, score, st);
+        case MKB_PROTATE: return launch_fwd<MKB_PROTATE>(T, sample, cand, B, (int)K, head, score, st);
+    }
+    return set_error(MKB_ERR_INVALID, "unknown model");
+}
+
+extern "C" int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const int64_t *cand,
+                             int64_t B, int64_t K, int mode, const float *dscore, void *stream) {
+    if (int rc = check_call(tb, sample, cand, B, K, mode)) return rc;
+    MKB_REQUIRE(gr && gr->g_ent && gr->g_rel && dscore, "null gradient buffer");
+    MKB_REQUIRE(tb->model != MKB_PROTATE || gr->g_modulus, "pRotatE needs g_modulus");
+    if (B == 0) return MKB_OK;
+    const TablesDev T = to_dev(tb);
+    hipStream_t st = (hipStream_t)stream;
+    const bool head = mode_is_head(mode);
+    switch (tb->model) {
+        case MKB_TRANSE: return launch_bwd<MKB_TRANSE>(T, *gr, sample, cand, B, (int)K, head, dscore, st);
+        case MKB_ROTATE: return launch_bwd<MKB_ROTATE>(T, *gr, sample, cand, B, (int)K, head, dscore, st);
+        case MKB_COMPLEX: return launch_bwd<MKB_COMPLEX>(T, *gr, sample, cand, B, (int)K, head, dscore, st);
+        case MKB_DISTMULT: return launch_bwd<MKB_DISTMULT>(T, *gr, sample, cand, B, (int)K, head, dscore, st);
+        case MKB_PROTATE: return launch_bwd<MKB_PROTATE>(T, *gr, sample, cand, B, (int)K, head, dscore, st);
+    }
+    return set_error(MKB_ERR_INVALID, "unknown model");
+}

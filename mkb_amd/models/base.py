@@ -1,0 +1,194 @@
+"""``BaseModel`` -- parameter tables + the dispatch from ``model(sample, negative_sample, mode)`` to the HIP
+scoring kernels (reference: mkb/models/base.py:49-219).
+
+Same constructor, parameter names (``entity_embedding``, ``relation_embedding``, ``gamma``,
+``embedding_range``, ``modulus``), init order (entity table first, then relation table, base.py:86-100) and
+call signature as the reference; ``forward`` is differentiable through a ``torch.autograd.Function`` whose
+backward fills dense gradients exactly like the reference's ``index_select`` backward does.
+
+Two kernel paths sit behind ``forward``:
+  * general  -- arbitrary ``negative_sample`` ids (``mkb_score_fwd`` / ``mkb_score_bwd``);
+  * pooled   -- ``negative_sample`` produced by ``mkb_amd.sampling.NegativeSampling`` on the device: all rows
+                draw from ONE shared pool (negative_sampling.py:166), so each pool row is loaded once per row
+                tile instead of once per (row, slot) (``mkb_pool_score_fwd`` / pooled backward).
+"""
+import math
+import pickle
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+
+__all__ = ["BaseModel"]
+
+
+class _ScoreFn(torch.autograd.Function):
+    """score = model.forward(...) on device; backward = dense d loss / d tables."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, modulus, model, sample, cand, mode):
+        B = sample.shape[0]
+        K = 1 if cand is None else cand.shape[1]
+        score = torch.empty((B, K), dtype=torch.float32, device=ent.device)
+        tb = model._tables(ent, rel, modulus)
+        with torch.cuda.device(ent.device):
+            _hip.check(_hip.lib().mkb_score_fwd(tb, _hip.ptr(sample), _hip.ptr(cand), B, K, mode, _hip.ptr(score),
+                                                _hip.stream_ptr()), "mkb_score_fwd")
+        ctx.model, ctx.mode = model, mode
+        ctx.save_for_backward(ent, rel, modulus, sample, cand)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        ent, rel, modulus, sample, cand = ctx.saved_tensors
+        model = ctx.model
+        B = sample.shape[0]
+        K = 1 if cand is None else cand.shape[1]
+        dscore = _hip.contiguous(dscore, torch.float32)
+        g_ent, g_rel = torch.zeros_like(ent), torch.zeros_like(rel)
+        g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
+        tb = model._tables(ent, rel, modulus)
+        gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
+        with torch.cuda.device(ent.device):
+            _hip.check(_hip.lib().mkb_score_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(cand), B, K, ctx.mode,
+                                                _hip.ptr(dscore), _hip.stream_ptr()), "mkb_score_bwd")
+        return g_ent, g_rel, g_mod, None, None, None, None
+
+
+class Base(nn.Module):
+    """mkb/models/base.py:9-46."""
+
+    @property
+    def name(self):
+        return self.__class__.__name__
+
+    @property
+    def _repr_title(self):
+        return f"{self.name} model"
+
+    @property
+    def _repr_content(self):
+        return {}
+
+    def __repr__(self):
+        l_len = max(map(len, self._repr_content.keys()))
+        r_len = max(map(len, self._repr_content.values()))
+        return f"{self._repr_title}\n" + "\n".join(
+            k.rjust(l_len) + "  " + v.ljust(r_len) for k, v in self._repr_content.items())
+
+    def save(self, path):
+        with open(path, "wb") as handle:
+            pickle.dump(self.cpu().eval(), handle, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+class BaseModel(Base):
+    def __init__(self, entities, relations, hidden_dim, entity_dim, relation_dim, gamma):
+        super().__init__()
+        self.entities = {i: e for e, i in entities.items()}
+        self.relations = {i: r for r, i in relations.items()}
+        self.n_entity = len(entities)
+        self.n_relation = len(relations)
+        self.hidden_dim = hidden_dim
+        self.entity_dim = entity_dim
+        self.relation_dim = relation_dim
+
+        self.gamma = nn.Parameter(torch.Tensor([gamma]), requires_grad=False)
+        self.epsilon = 2
+        self.embedding_range = nn.Parameter(
+            torch.Tensor([(self.gamma.item() + self.epsilon) / self.hidden_dim]), requires_grad=False)
+
+        self.entity_embedding = nn.Parameter(torch.zeros(self.n_entity, self.entity_dim))
+        nn.init.uniform_(tensor=self.entity_embedding, a=-self.embedding_range.item(), b=self.embedding_range.item())
+        self.relation_embedding = nn.Parameter(torch.zeros(self.n_relation, self.relation_dim))
+        nn.init.uniform_(tensor=self.relation_embedding, a=-self.embedding_range.item(),
+                         b=self.embedding_range.item())
+        self._consts = None
+
+    # ------------------------------------------------------------------ host-side constants
+    def _constants(self):
+        """(gamma, phase_div) as python floats; read once (each .item() is a device sync) and refreshed when
+        the parameters are replaced (``_set_params``, ``.to()``, ``load_state_dict``)."""
+        if self._consts is None:
+            gamma = self.gamma.item()
+            phase_div = torch.tensor(self.embedding_range.item() / math.pi, dtype=torch.float32).item()
+            self._consts = (gamma, phase_div)
+        return self._consts
+
+    def _apply(self, fn, *args, **kwargs):
+        self._consts = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._consts = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _tables(self, ent=None, rel=None, modulus=None):
+        ent = self.entity_embedding if ent is None else ent
+        rel = self.relation_embedding if rel is None else rel
+        if modulus is None:
+            modulus = getattr(self, "modulus", None)
+        gamma, phase_div = self._constants()
+        return _hip.Tables(_hip.MODEL_IDS[self.name], self.hidden_dim, self.n_entity, self.n_relation, self.entity_dim,
+                           self.relation_dim, ent.data_ptr(), rel.data_ptr(),
+                           None if modulus is None else modulus.data_ptr(), gamma, phase_div)
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def embeddings(self):
+        ent = self.entity_embedding.detach()
+        rel = self.relation_embedding.detach()
+        return {"entities": {self.entities[i]: ent[i] for i in range(self.n_entity)},
+                "relations": {self.relations[i]: rel[i] for i in range(self.n_relation)}}
+
+    @property
+    def _repr_content(self):
+        return {
+            "Entities embeddings dim": f"{self.entity_dim}",
+            "Relations embeddings dim": f"{self.relation_dim}",
+            "Gamma": f"{self._constants()[0]}",
+            "Number of entities": f"{self.n_entity}",
+            "Number of relations": f"{self.n_relation}",
+        }
+
+    @staticmethod
+    def format_sample(sample, negative_sample=None):
+        """base.py:131-151."""
+        if sample.dim() == 2:
+            if negative_sample is None:
+                return sample, (sample.size(0), 1)
+            return sample, negative_sample.shape
+        if sample.dim() == 3:
+            return sample.reshape(sample.size(0) * sample.size(1), 3), (sample.size(0), sample.size(1))
+        raise ValueError("sample must be [B,3] or [B,M,3]")
+
+    def forward(self, sample, negative_sample=None, mode=None):
+        _hip.require_device(self.entity_embedding, sample, negative_sample)
+        sample, shape = self.format_sample(sample=sample, negative_sample=negative_sample)
+        mode_id = _hip.mode_id(mode)
+        sample = _hip.contiguous(sample, torch.int64)
+        cand = None
+        if mode_id != _hip.MODE_DEFAULT:
+            pooled = getattr(negative_sample, "_mkb_pool", None)
+            if pooled is not None and pooled.usable_for(self, sample, mode_id):
+                from ..fused import pooled_forward
+                return pooled_forward(self, sample, pooled, mode_id).view(shape)
+            cand = _hip.contiguous(negative_sample, torch.int64)
+        modulus = getattr(self, "modulus", None)
+        if modulus is None:  # autograd.Function needs a tensor slot; never read by the kernels
+            modulus = self.gamma
+        score = _ScoreFn.apply(self.entity_embedding, self.relation_embedding, modulus, self, sample, cand, mode_id)
+        return score.view(shape)
+
+    def _set_params(self, entities_embeddings, relations_embeddings, **kwargs):
+        """base.py:209-215."""
+        self.entity_embedding.data.copy_(entities_embeddings)
+        self.relation_embedding.data.copy_(relations_embeddings)
+        for parameter, weights in kwargs.items():
+            self._parameters[parameter].data.copy_(weights)
+        self._consts = None
+        return self
+
+    def distill(self, sample, negative_sample=None, mode=None):
+        """base.py:217-219."""
+        return self(sample=sample, negative_sample=negative_sample, mode=mode)

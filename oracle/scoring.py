@@ -199,7 +199,7 @@ def train_step_grads(tb: Tables, sample, negative_sample, weight, mode, alpha, f
 def adam_update(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     """torch.optim.Adam (single-tensor, no amsgrad/weight decay) as the README loop uses it
     (README.md:123-126).  ``step`` is 1-based.  In-place on p, m, v; dense: every row moves."""
-    m.mul_(b1).add_(g, alpha=1 - b1)
+    m.lerp_(g, 1 - b1)
     v.mul_(b2).addcmul_(g, g, value=1 - b2)
     bc1 = 1 - b1 ** step
     bc2 = 1 - b2 ** step

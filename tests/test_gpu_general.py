@@ -1,0 +1,123 @@
+"""-m gpu: general (arbitrary-candidate) scoring path, loss and Adam through the C ABI vs the oracle and the
+golden vectors captured from the live reference.  Tolerance: 1e-4 absolute fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"]
+MODES = [None, "head-batch", "tail-batch"]
+ATOL = 1e-4
+
+
+def _golden_model(g, name):
+    from util_gpu import make_model
+
+    N, R, hid, B, K = (int(v) for v in g["meta"])
+    mod = g[f"{name}/modulus"] if f"{name}/modulus" in g.files else None
+    return make_model(name, g[f"{name}/ent"], g[f"{name}/rel"], hid, float(g["gamma"]), mod)
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("mode", MODES)
+def test_scores_vs_reference_golden(golden, name, mode):
+    g = golden("models.npz")
+    m = _golden_model(g, name)
+    s = torch.as_tensor(g["sample"]).cuda()
+    n = torch.as_tensor(g["neg"]).cuda()
+    got = m(s, None if mode is None else n, mode)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), g[f"{name}/{mode}/score"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_3d_sample(golden, name):
+    g = golden("models.npz")
+    m = _golden_model(g, name)
+    got = m(torch.as_tensor(g["sample3d"]).cuda())
+    np.testing.assert_allclose(got.detach().cpu().numpy(), g[f"{name}/score3d"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("mode", MODES[1:])
+def test_loss_and_dense_grads_vs_reference_golden(golden, name, mode):
+    from mkb_amd import losses
+
+    g = golden("models.npz")
+    m = _golden_model(g, name)
+    s, n = torch.as_tensor(g["sample"]).cuda(), torch.as_tensor(g["neg"]).cuda()
+    w = torch.as_tensor(g["weight"]).cuda()
+    err = losses.Adversarial(alpha=float(g["alpha"]))(m(s), m(s, n, mode), w)
+    err.backward()
+    tag = f"{name}/{mode}"
+    np.testing.assert_allclose(err.item(), g[f"{tag}/loss"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), g[f"{tag}/g_ent"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), g[f"{tag}/g_rel"], rtol=1e-4, atol=1e-5)
+    if name == "pRotatE":
+        np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), g[f"{tag}/g_modulus"], rtol=1e-4)
+    if name == "RotatE":
+        assert m.modulus.grad is None  # unused parameter, as in the reference
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_adam_trajectory_vs_reference_golden(golden, name):
+    """3 x (pos fwd, neg fwd, Adversarial, backward, mkb_adam_step + zero) == reference torch.optim.Adam."""
+    from mkb_amd import losses, optim
+
+    g = golden("models.npz")
+    m = _golden_model(g, name)
+    s, n = torch.as_tensor(g["sample"]).cuda(), torch.as_tensor(g["neg"]).cuda()
+    w = torch.as_tensor(g["weight"]).cuda()
+    opt = optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=0.01)
+    lossf = losses.Adversarial(alpha=float(g["alpha"]))
+    traj = []
+    for step in range(3):
+        mode = MODES[1 + step % 2]
+        err = lossf(m(s), m(s, n, mode), w)
+        err.backward()
+        opt.step()
+        opt.zero_grad()
+        traj.append(err.item())
+    np.testing.assert_allclose(traj, g[f"{name}/adam/loss"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m.entity_embedding.detach().cpu().numpy(), g[f"{name}/adam/ent"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m.relation_embedding.detach().cpu().numpy(), g[f"{name}/adam/rel"], rtol=0, atol=1e-5)
+    if name == "pRotatE":
+        np.testing.assert_allclose(m.modulus.detach().cpu().numpy(), g[f"{name}/adam/modulus"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("mode", MODES[1:])
+@pytest.mark.parametrize("shape", [(300, 7, 64, 33, 16), (2000, 11, 250, 64, 50)])
+def test_random_problem_vs_oracle(name, mode, shape):
+    """Seeded mid-size problems (odd dims, duplicates inevitable) vs the torch-fp32 oracle and the float64
+    closed form."""
+    from mkb_amd import losses
+    from oracle import closed, scoring
+    from util_gpu import make_model, oracle_tables, random_problem
+
+    N, R, hid, B, K = shape
+    ent, rel, s, n, w, mod = random_problem(name, N, R, hid, B, K, seed=hash((name, mode, N)) % 1000)
+    m = make_model(name, ent, rel, hid, 6.0, mod)
+    tb = oracle_tables(name, ent, rel, hid, 6.0, mod)
+    ref = scoring.train_step_grads(tb, s, n, w, mode, 1.0, fast_norm=True)
+    pos, neg = m(s.cuda()), m(s.cuda(), n.cuda(), mode)
+    np.testing.assert_allclose(pos.detach().cpu().numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(neg.detach().cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+    err = losses.Adversarial(alpha=1.0)(pos, neg, w.cuda())
+    err.backward()
+    np.testing.assert_allclose(err.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+    c = closed.train_step_grads(name, ent.numpy(), rel.numpy(), s.numpy(), n.numpy(), w.numpy(), mode, 1.0, 6.0, hid,
+                                None if mod is None else mod.numpy())
+    ge = m.entity_embedding.grad.cpu().numpy()
+    gr = m.relation_embedding.grad.cpu().numpy()
+    np.testing.assert_allclose(ge, ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(ge, c["g_ent"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(gr, c["g_rel"], rtol=1e-4, atol=1e-5)
+
+
+def test_cpu_tensors_are_rejected():
+    from mkb_amd import models
+
+    m = models.TransE(hidden_dim=4, entities={0: 0, 1: 1}, relations={0: 0}, gamma=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor([[0, 0, 1]]))

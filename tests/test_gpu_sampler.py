@@ -1,0 +1,106 @@
+"""-m gpu: the on-device sampler must be BIT-EXACT with the reference (golden negatives from the live
+reference + the numpy/C oracle on seeded batches)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_doctest_known_answers(golden):
+    """sampling/negative_sampling.py:101-103, 120-122 (size=5, seed 42, 4-entity toy graph)."""
+    from mkb_amd import sampling
+
+    ents, rels = {i: i for i in range(4)}, {i: i for i in range(4)}
+    train = [(0, 0, 1), (1, 0, 2), (2, 0, 3), (3, 0, 1)]
+    ns = sampling.NegativeSampling(size=5, train_triples=train, entities=ents, relations=rels, seed=42)
+    smp = torch.tensor([[0, 0, 1], [1, 0, 2]]).cuda()
+    tail = ns.generate(smp, mode="tail-batch")
+    head = ns.generate(smp, mode="head-batch")
+    assert tail.dtype == torch.int64 and tail.shape == (2, 5)
+    np.testing.assert_array_equal(tail.cpu().numpy(), [[2, 3, 0, 2, 2], [3, 0, 3, 0, 0]])
+    np.testing.assert_array_equal(head.cpu().numpy(), [[2, 2, 2, 2, 2], [2, 2, 2, 2, 3]])
+
+
+@pytest.mark.parametrize("cls", ["Umls", "Wn18rr", "Fb15k237"])
+def test_real_graph_negatives_bit_exact(golden, cls):
+    from mkb_amd import datasets, sampling
+
+    g = golden("sampler.npz")
+    K = int(g[f"{cls}/K"])
+    ds = getattr(datasets, cls)(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    c = 0
+    while f"{cls}/{c}/idx" in g.files:
+        smp = train[torch.as_tensor(g[f"{cls}/{c}/idx"].astype(np.int64)).cuda()]
+        mode = "head-batch" if c % 2 == 0 else "tail-batch"
+        neg = ns.generate(smp, mode)
+        np.testing.assert_array_equal(neg.cpu().numpy(), g[f"{cls}/{c}/neg"].astype(np.int64))
+        info = neg._mkb_pool
+        # side outputs are consistent: neg == pool[pos]; cnt == histogram of pos
+        np.testing.assert_array_equal(info.pool[info.pos.long()].cpu().numpy(), neg.cpu().numpy())
+        hist = torch.zeros(neg.shape[0], 2 * K, dtype=torch.int64, device="cuda")
+        hist.scatter_add_(1, info.pos.long(), torch.ones_like(info.pos, dtype=torch.int64))
+        np.testing.assert_array_equal(info.cnt.cpu().numpy().astype(np.int64), hist.cpu().numpy())
+        c += 1
+    ns.check()
+    assert c >= 4
+
+
+def test_long_stream_vs_c_oracle(liboracle):
+    """Headline shape: FB15k-237, K=256, B=1024, 40 consecutive batches alternating modes (the MT19937 block
+    boundary is crossed many times) vs the plain-C restatement."""
+    import ctypes
+
+    from mkb_amd import datasets, sampling
+    from mkb_amd.sampling.negative_sampling import _filter_csr
+
+    ds = datasets.Fb15k237(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    train_np = np.asarray(ds.train, dtype=np.int64)
+    train = torch.as_tensor(train_np).cuda()
+    K, B, N, R = 256, 1024, ds.n_entity, ds.n_relation
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=7)
+    (hk, ho, hv, _), (tk, to, tv, _) = _filter_csr(ds.train, N, R)
+    st = ctypes.create_string_buffer(4 * 624 + 4)
+    liboracle.orc_mt_seed(st, ctypes.c_uint32(7))
+    liboracle.orc_generate.restype = ctypes.c_int
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    pick = np.random.RandomState(3)
+    for c in range(40):
+        idx = pick.randint(len(train_np), size=B)
+        head = c % 2 == 0
+        got = ns.generate(train[torch.as_tensor(idx).cuda()], "head-batch" if head else "tail-batch")
+        smp = np.ascontiguousarray(train_np[idx])
+        want = np.zeros((B, K), dtype=np.int64)
+        pool = np.zeros(2 * K, dtype=np.int64)
+        k, o, v, stride = (hk, ho, hv, N) if head else (tk, to, tv, R)
+        rc = liboracle.orc_generate(st, ctypes.c_int64(N), ctypes.c_int64(K), p(smp), ctypes.c_int64(B), ctypes.c_int(head),
+                                    p(k), ctypes.c_int64(len(k)), p(o), p(v), ctypes.c_int64(stride), p(want), p(pool))
+        assert rc == 0
+        np.testing.assert_array_equal(got._mkb_pool.pool.cpu().numpy(), pool)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    key, pos = ns.get_state()
+    ref = np.frombuffer(st.raw[: 4 * 624], dtype=np.uint32)
+    np.testing.assert_array_equal(key, ref)
+    assert pos == int(np.frombuffer(st.raw[4 * 624:], dtype=np.int32)[0])
+
+
+def test_unseen_key_raises_keyerror():
+    from mkb_amd import sampling
+
+    ents, rels = {i: i for i in range(4)}, {i: i for i in range(2)}
+    ns = sampling.NegativeSampling(size=3, train_triples=[(0, 0, 1), (1, 0, 2)], entities=ents, relations=rels, seed=1)
+    ns.generate(torch.tensor([[0, 0, 1], [3, 1, 0]]).cuda(), "tail-batch")
+    with pytest.raises(KeyError):
+        ns.check()
+
+
+def test_empty_filter_raises_instead_of_hanging():
+    from mkb_amd import sampling
+
+    ents, rels = {i: i for i in range(2)}, {0: 0}
+    ns = sampling.NegativeSampling(size=3, train_triples=[(0, 0, 0), (0, 0, 1)], entities=ents, relations=rels, seed=1)
+    ns.generate(torch.tensor([[0, 0, 1]]).cuda(), "tail-batch")  # true tails of (0,0) = {0,1} = every entity
+    with pytest.raises(RuntimeError, match="whole candidate pool"):
+        ns.check()

@@ -1,0 +1,42 @@
+"""Helpers shared by the -m gpu parity tests: build an mkb_amd model on the device from raw tables."""
+import numpy as np
+import torch
+
+import mkb_amd
+from mkb_amd import models
+from oracle import scoring
+
+DEV = "cuda"
+
+
+def make_model(name, ent, rel, hidden, gamma, modulus=None):
+    N, R = ent.shape[0], rel.shape[0]
+    m = getattr(models, name)(hidden_dim=hidden, entities={i: i for i in range(N)}, relations={i: i for i in range(R)},
+                              gamma=gamma)
+    with torch.no_grad():
+        m.entity_embedding.copy_(torch.as_tensor(ent))
+        m.relation_embedding.copy_(torch.as_tensor(rel))
+        if modulus is not None and hasattr(m, "modulus"):
+            m.modulus.copy_(torch.as_tensor(modulus))
+    return m.to(DEV)
+
+
+def oracle_tables(name, ent, rel, hidden, gamma, modulus=None):
+    mod = None
+    if name in ("RotatE", "pRotatE"):
+        mod = torch.as_tensor(modulus).clone().float() if modulus is not None else None
+    return scoring.Tables(name, hidden, gamma, torch.as_tensor(ent).clone().float(), torch.as_tensor(rel).clone().float(), mod)
+
+
+def random_problem(name, N, R, hidden, B, K, seed, gamma=6.0):
+    g = torch.Generator().manual_seed(seed)
+    de, dr = scoring.dims(name, hidden)
+    rng = (gamma + 2.0) / hidden
+    ent = (torch.rand(N, de, generator=g) * 2 - 1) * rng
+    rel = (torch.rand(R, dr, generator=g) * 2 - 1) * rng
+    sample = torch.stack([torch.randint(N, (B,), generator=g), torch.randint(R, (B,), generator=g),
+                          torch.randint(N, (B,), generator=g)], 1)
+    neg = torch.randint(N, (B, K), generator=g)
+    w = torch.rand(B, generator=g) + 0.1
+    modulus = torch.tensor([[0.5 * rng]]) if name in ("RotatE", "pRotatE") else None
+    return ent, rel, sample, neg, w, modulus
