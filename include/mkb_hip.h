@@ -122,9 +122,13 @@ int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t
 int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                   const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
                   float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
-/* forward only (pooled model.forward): pool_score [B,2K] */
+/* pooled model.forward / its autograd as separate calls (README-style loops that call the model and the loss
+ * themselves): pool_score [B,2K] out; dpool_score [B,2K] = d loss / d pool_score in. */
 int mkb_pool_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
                        int64_t B, int64_t K, int mode, float *pool_score, void *ws, void *stream);
+int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
+                       const uint16_t *cnt, int64_t B, int64_t K, int mode, const float *dpool_score, void *ws,
+                       void *stream);
 
 /* ---- dense Adam --------------------------------------------------------------------------------------
  * == torch.optim.Adam(lr, betas, eps).step() + zero_grad() for one parameter tensor as the README loop

@@ -17,6 +17,6 @@ library raises at first use.
 """
 __version__ = "0.1.0"
 
-from . import compose, datasets, evaluation, losses, models, sampling, utils  # noqa: F401
+from . import compose, datasets, evaluation, fused, losses, models, optim, sampling, utils  # noqa: F401
 
-__all__ = ["compose", "datasets", "evaluation", "losses", "models", "sampling", "utils"]
+__all__ = ["compose", "datasets", "evaluation", "fused", "losses", "models", "optim", "sampling", "utils"]

@@ -60,6 +60,8 @@ _SIGNATURES = {
                               c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_pool_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p]),
+    "mkb_pool_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                   c_void_p, c_void_p, c_void_p]),
     "mkb_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
                               c_float, c_int, c_void_p]),
     "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,

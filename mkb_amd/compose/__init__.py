@@ -1,1 +1,3 @@
+from .pipeline import Pipeline
 
+__all__ = ["Pipeline"]

@@ -1,1 +1,3 @@
+from .evaluation import Evaluation
 
+__all__ = ["Evaluation"]

@@ -1,5 +1,125 @@
-"""Pooled (shared-candidate-pool) scoring path -- filled in with the pooled kernels."""
+"""Pooled (shared-candidate-pool) scoring path and the fused training step.
+
+``pooled_forward``   -- what ``model(sample, negative_sample, mode)`` runs when ``negative_sample`` came from
+                        ``mkb_amd.sampling.NegativeSampling`` on the device: ``mkb_pool_score_fwd`` scores every
+                        row against the shared pool once, the ``[B, size]`` view is a gather; backward scatters
+                        ``d loss / d score`` back onto pool positions and calls ``mkb_pool_score_bwd``.
+``FusedTrainStep``   -- one call = lines 211-236 of the reference's compose/pipeline.py (positive forward,
+                        negative forward, Adversarial, backward into dense ``.grad``) through ``mkb_pool_step``,
+                        bypassing autograd.  Used by ``compose.Pipeline`` when model / sampler / loss are ours.
+"""
+import torch
+
+from . import _hip
+from .sampling.negative_sampling import PoolInfo
+
+__all__ = ["FusedTrainStep", "pooled_forward"]
+
+_workspaces = {}
 
 
-def pooled_forward(model, sample, pooled, mode_id):
-    raise NotImplementedError
+def _workspace(model, B, K):
+    """Device scratch for the pooled kernels, cached per (device, table shape, B, K)."""
+    dev = model.entity_embedding.device
+    key = (dev, model.name, model.entity_dim, B, K)
+    ws = _workspaces.get(key)
+    if ws is None:
+        n = _hip.lib().mkb_pool_step_workspace_bytes(model._tables(), B, K)
+        ws = torch.empty(n + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        ws = ws[off: off + n]
+        _workspaces[key] = ws
+    return ws
+
+
+def _supported(K):
+    return 2 * K <= 1024
+
+
+class _PoolScoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ent, rel, modulus, model, sample, info, mode):
+        B, K = sample.shape[0], info.size
+        S = torch.empty((B, 2 * K), dtype=torch.float32, device=ent.device)
+        ws = _workspace(model, B, K)
+        with torch.cuda.device(ent.device):
+            _hip.check(_hip.lib().mkb_pool_score_fwd(model._tables(ent, rel, modulus), _hip.ptr(sample), _hip.ptr(info.pool),
+                                                     _hip.ptr(info.cnt), B, K, mode, _hip.ptr(S), _hip.ptr(ws),
+                                                     _hip.stream_ptr()), "mkb_pool_score_fwd")
+        ctx.model, ctx.info, ctx.mode = model, info, mode
+        ctx.save_for_backward(ent, rel, modulus, sample)
+        return S.gather(1, info.pos.long())
+
+    @staticmethod
+    def backward(ctx, dneg):
+        ent, rel, modulus, sample = ctx.saved_tensors
+        model, info = ctx.model, ctx.info
+        B, K = sample.shape[0], info.size
+        G = torch.zeros((B, 2 * K), dtype=torch.float32, device=ent.device)
+        G.scatter_add_(1, info.pos.long(), _hip.contiguous(dneg, torch.float32))
+        g_ent, g_rel = torch.zeros_like(ent), torch.zeros_like(rel)
+        g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
+        gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
+        ws = _workspace(model, B, K)
+        with torch.cuda.device(ent.device):
+            _hip.check(_hip.lib().mkb_pool_score_bwd(model._tables(ent, rel, modulus), gr, _hip.ptr(sample),
+                                                     _hip.ptr(info.pool), _hip.ptr(info.cnt), B, K, ctx.mode, _hip.ptr(G),
+                                                     _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_score_bwd")
+        return g_ent, g_rel, g_mod, None, None, None, None
+
+
+def pooled_forward(model, sample, info, mode_id):
+    modulus = getattr(model, "modulus", None)
+    if modulus is None:
+        modulus = model.gamma
+    return _PoolScoreFn.apply(model.entity_embedding, model.relation_embedding, modulus, model, sample, info, mode_id)
+
+
+PoolInfo.enabled = True
+PoolInfo.supported = staticmethod(_supported)
+
+
+class FusedTrainStep:
+    """``loss = step(sample, weight, negative_sample, mode)``: fills ``param.grad`` (dense, accumulated) and returns
+    the loss as a 0-dim device tensor.  ``positive_score`` [B,1] and ``negative_score`` [B,size] of the last call
+    stay available for inspection."""
+
+    def __init__(self, model, alpha):
+        self.model, self.alpha = model, float(alpha)
+        self._grads = None
+
+    def _grad_buffers(self):
+        m = self.model
+        params = [m.entity_embedding, m.relation_embedding] + ([m.modulus] if m.name == "pRotatE" else [])
+        for p in params:
+            if p.grad is None:  # first step, or the optimizer's zero_grad(set_to_none=True)
+                p.grad = torch.zeros_like(p)
+        return _hip.Grads(m.entity_embedding.grad.data_ptr(), m.relation_embedding.grad.data_ptr(),
+                          m.modulus.grad.data_ptr() if m.name == "pRotatE" else None)
+
+    def __call__(self, sample, weight, negative_sample, mode):
+        m = self.model
+        info = getattr(negative_sample, "_mkb_pool", None)
+        if info is None:
+            raise ValueError("negative_sample does not come from mkb_amd.sampling.NegativeSampling.generate")
+        mode_id = _hip.mode_id(mode)
+        sample = _hip.contiguous(sample, torch.int64)
+        weight = _hip.contiguous(weight, torch.float32)
+        _hip.require_device(m.entity_embedding, sample, weight)
+        B, K = sample.shape[0], info.size
+        dev = sample.device
+        pos = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        S = torch.empty((B, 2 * K), dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = _workspace(m, B, K)
+        gr = self._grad_buffers()
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
+                                                _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(pos), _hip.ptr(S),
+                                                _hip.ptr(loss), _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_step")
+        self.positive_score, self._S, self._info = pos, S, info
+        return loss.reshape(())
+
+    @property
+    def negative_score(self):
+        return self._S.gather(1, self._info.pos.long())

@@ -1,4 +1,5 @@
 from .bar import Bar, BarRange
 from .io import read_csv, read_json
+from .stats import Mean, RollingMean
 
-__all__ = ["Bar", "BarRange", "read_csv", "read_json"]
+__all__ = ["Bar", "BarRange", "Mean", "RollingMean", "read_csv", "read_json"]

@@ -1,0 +1,189 @@
+"""-m gpu: pooled (shared candidate pool) path and the fused training step vs the oracle, on real graphs with
+negatives from the on-device sampler; Pipeline.learn vs the step-by-step capture of the live reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MODELS = ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"]
+ATOL = 1e-4
+
+
+def _setup(cls, name, hidden, B, K, gamma=6.0, seed=0):
+    from mkb_amd import datasets, models, sampling
+    from oracle import scoring
+
+    ds = getattr(datasets, cls)(batch_size=B, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(seed)
+    m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=gamma)
+    tb = scoring.Tables(name, hidden, gamma, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(),
+                        m.modulus.detach().clone() if hasattr(m, "modulus") else None)
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64))
+    return ds, m.cuda(), tb, ns, train
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("mode", ["head-batch", "tail-batch"])
+def test_pooled_forward_backward_equals_general_and_oracle(name, mode):
+    from mkb_amd import losses
+    from oracle import scoring
+
+    ds, m, tb, ns, train = _setup("Umls", name, 50, 77, 16)
+    idx = torch.as_tensor(np.random.RandomState(1).randint(len(train), size=77))
+    s = train[idx].cuda()
+    w = (torch.rand(77) + 0.1).cuda()
+    neg = ns.generate(s, mode)
+    assert neg._mkb_pool is not None
+    plain = neg.clone()  # no pool info -> general kernels
+    assert not hasattr(plain, "_mkb_pool")
+    ref = scoring.train_step_grads(tb, s.cpu(), neg.cpu(), w.cpu(), mode, 0.5, fast_norm=True)
+
+    got = {}
+    for tag, n in (("pooled", neg), ("general", plain)):
+        m.zero_grad()
+        sc = m(s, n, mode)
+        np.testing.assert_allclose(sc.detach().cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        err = losses.Adversarial(alpha=0.5)(m(s), sc, w)
+        err.backward()
+        np.testing.assert_allclose(err.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+        got[tag] = (m.entity_embedding.grad.cpu().numpy().copy(), m.relation_embedding.grad.cpu().numpy().copy())
+        np.testing.assert_allclose(got[tag][0], ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got[tag][1], ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        if name == "pRotatE":
+            np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
+    ns.check()
+
+
+@pytest.mark.parametrize("cls,name,hidden,B,K", [
+    ("Umls", "TransE", 64, 256, 16),          # BASELINE config 1 shape
+    ("Wn18rr", "RotatE", 32, 200, 128),       # config 2 sampler shape, reduced dim (oracle in seconds)
+    ("Fb15k237", "RotatE", 40, 160, 256),     # headline sampler shape, reduced dim
+    ("Fb15k237", "ComplEx", 40, 160, 256),    # config 4
+    ("Fb15k237", "DistMult", 33, 96, 256),
+    ("Fb15k237", "pRotatE", 24, 96, 256),
+])
+def test_fused_step_vs_oracle_real_graphs(cls, name, hidden, B, K):
+    from mkb_amd.fused import FusedTrainStep
+    from oracle import scoring
+
+    ds, m, tb, ns, train = _setup(cls, name, hidden, B, K, gamma=9.0)
+    step = FusedTrainStep(m, alpha=1.0)
+    pick = np.random.RandomState(7)
+    for c, mode in enumerate(["head-batch", "tail-batch", "head-batch"]):
+        idx = torch.as_tensor(pick.randint(len(train), size=B))
+        s = train[idx].cuda()
+        w = (torch.rand(B) + 0.1).cuda()
+        m.zero_grad(set_to_none=True)
+        neg = ns.generate(s, mode)
+        loss = step(s, w, neg, mode)
+        ref = scoring.train_step_grads(tb, s.cpu(), neg.cpu(), w.cpu(), mode, 1.0, fast_norm=True)
+        np.testing.assert_allclose(step.positive_score.cpu().numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        if name == "pRotatE":
+            np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
+    ns.check()
+
+
+def test_headline_slice_vs_reference_golden(golden):
+    """FB15k-237 RotatE hidden=1000 K=256: 16 rows of a real batch vs scores captured from the live reference."""
+    from mkb_amd import datasets, models
+
+    g = golden("headline_slice.npz")
+    ds = datasets.Fb15k237(batch_size=16, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(42)
+    m = models.RotatE(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9)
+    if not np.array_equal(m.entity_embedding[[0, 7270, 14540]].detach().numpy(), g["ent_rows_pin"]):
+        pytest.skip("torch CPU RNG stream differs from the build container's")
+    m = m.cuda()
+    s = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)[g["idx"]]).cuda()
+    np.testing.assert_allclose(m(s).detach().cpu().numpy(), g["pos"], rtol=0, atol=ATOL)
+    for mode in ["head-batch", "tail-batch"]:
+        neg = torch.as_tensor(g[f"{mode}/neg"].astype(np.int64)).cuda()
+        np.testing.assert_allclose(m(s, neg, mode).detach().cpu().numpy(), g[f"{mode}/score"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_pipeline_countries_vs_reference_capture(golden, fuse, capsys):
+    """compose/pipeline.py:79-129 setup: CountriesS1 bs=20 seed 42, RotatE hidden 5 gamma 3, K=4, Adam 5e-5,
+    alpha .5, 3 epochs, eval every epoch.  Every step's (sample, negatives, loss) and the final tables / metrics
+    must reproduce the capture of the live reference."""
+    from mkb_amd import compose, datasets, evaluation, losses, models, sampling
+
+    g = golden("pipeline_countries.npz")
+    gj = golden("pipeline_countries.json")
+    torch.manual_seed(42)
+    ds = datasets.CountriesS1(batch_size=20, seed=42)
+    model = models.RotatE(hidden_dim=5, entities=ds.entities, relations=ds.relations, gamma=3)
+    np.testing.assert_array_equal(model.entity_embedding.detach().numpy(), g["ent0"])
+    model = model.cuda()
+    ns = sampling.NegativeSampling(size=4, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=0.00005)
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=8,
+                               device="cuda")
+    rec = {"sample": [], "neg": [], "loss": []}
+    gen0 = ns.generate
+
+    def gen(sample, mode):
+        n = gen0(sample=sample, mode=mode)
+        rec["sample"].append(sample.cpu().numpy())
+        rec["neg"].append(n.cpu().numpy())
+        return n
+
+    ns.generate = gen
+    pipe = compose.Pipeline(epochs=3, eval_every=1, early_stopping_rounds=3, device="cuda")
+    pipe.fuse = fuse
+    upd0 = pipe.metric_loss.update
+    pipe.metric_loss.update = lambda x: (rec["loss"].append(x), upd0(x))[1]
+    pipe = pipe.learn(model=model, dataset=ds, evaluation=ev, sampling=ns, optimizer=opt, loss=losses.Adversarial(alpha=0.5))
+    assert len(rec["sample"]) == int(g["steps"])
+    for i, (s, n) in enumerate(zip(rec["sample"], rec["neg"])):
+        np.testing.assert_array_equal(s, g[f"step{i}/sample"])
+        np.testing.assert_array_equal(n, g[f"step{i}/neg"])
+    np.testing.assert_allclose(rec["loss"], g["loss"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(model.entity_embedding.detach().cpu().numpy(), g["ent_final"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(model.relation_embedding.detach().cpu().numpy(), g["rel_final"], rtol=0, atol=2e-5)
+    for split in ("valid_scores", "test_scores"):
+        for k, v in gj[split].items():
+            assert abs(getattr(pipe, split)[k] - v) <= (0.5 if k.startswith("MR") and not k.startswith("MRR") else 0.02), (split, k)
+
+
+def test_evaluation_doctest_known_answer(golden):
+    """evaluation/evaluation.py:43-119: trained toy RotatE -> {'MRR': 0.5417, 'MR': 2.25, 'HITS@1': 0.25, ...}."""
+    from mkb_amd import evaluation, models
+
+    g = golden("evaluation.npz")
+    gj = golden("evaluation.json")
+    ents = {f"e{i}": i for i in range(4)}
+    rels = {"r0": 0, "r1": 1}
+    m = models.RotatE(hidden_dim=3, entities=ents, relations=rels, gamma=1)
+    m._set_params(torch.as_tensor(g["ent"]), torch.as_tensor(g["rel"]))
+    m = m.cuda().eval()
+    train = [(0, 0, 1), (0, 1, 1), (2, 0, 3), (2, 1, 3)]
+    test = [(0, 0, 1), (2, 1, 3)]
+    ev = evaluation.Evaluation(true_triples=train + test + test, entities=ents, relations=rels, batch_size=2, device="cuda")
+    assert ev.eval(model=m, dataset=test) == gj["toy_eval"] == {"MRR": 0.5417, "MR": 2.25, "HITS@1": 0.25, "HITS@3": 1.0, "HITS@10": 1.0}
+    assert ev.eval_relations(model=m, dataset=test) == gj["toy_eval_relations"]
+
+
+@pytest.mark.parametrize("name", ["TransE", "ComplEx", "RotatE"])
+def test_evaluation_countries_vs_reference(golden, name):
+    from mkb_amd import datasets, evaluation, models
+
+    g = golden("evaluation.npz")
+    gj = golden("evaluation.json")
+    ds = datasets.CountriesS1(batch_size=20, seed=42)
+    m = getattr(models, name)(hidden_dim=6, entities=ds.entities, relations=ds.relations, gamma=4)
+    m._set_params(torch.as_tensor(g[f"countries/{name}/ent"]), torch.as_tensor(g[f"countries/{name}/rel"]))
+    m = m.cuda().eval()
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=8,
+                               device="cuda")
+    for split in ("test", "valid"):
+        got = ev.eval(model=m, dataset=getattr(ds, split))
+        want = gj[f"countries/{name}/{split}"]
+        for k in want:
+            assert abs(got[k] - want[k]) <= (0.1 if k == "MR" else 2e-3), (split, k, got, want)

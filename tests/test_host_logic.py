@@ -1,0 +1,125 @@
+"""CPU (-m "not gpu") tests of the host side: dataset producers vs golden captures of the reference, the C-ABI
+library's exported symbols, and loud failure without a device."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    """include/mkb_hip.h <-> libmkb_hip.so <-> mkb_amd/_hip.py agree (no compute calls: there is no GPU here)."""
+    from conftest import ROOT
+    from mkb_amd import _hip
+
+    header = (ROOT / "include" / "mkb_hip.h").read_text()
+    declared = set(re.findall(r"\b(mkb_[a-z_]+)\s*\(", header)) - {"mkb_sampler"}
+    lib = ctypes.CDLL(str(ROOT / "mkb_amd" / "libmkb_hip.so"))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mkb_hip.h but not exported"
+    assert declared == set(_hip.EXPORTED_SYMBOLS), declared ^ set(_hip.EXPORTED_SYMBOLS)
+    assert _hip.lib().mkb_abi_version() == _hip.ABI_VERSION
+
+
+def test_invalid_arguments_are_reported_not_crashed():
+    from mkb_amd import _hip
+
+    lib = _hip.lib()
+    tb = _hip.Tables(99, 4, 10, 2, 4, 4, None, None, None, 1.0, 1.0)
+    rc = lib.mkb_score_fwd(tb, None, None, 1, 1, 0, None, None)
+    assert rc == -1 and b"model" in lib.mkb_last_error()
+    assert lib.mkb_adam_step(None, None, None, None, 4, 1, 0.1, 0.9, 0.999, 1e-8, 0, None) == -1
+
+
+def test_no_cpu_fallback():
+    from mkb_amd import losses, models
+
+    m = models.RotatE(hidden_dim=4, entities={0: 0, 1: 1}, relations={0: 0}, gamma=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor([[0, 0, 1]]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        losses.Adversarial()(torch.zeros(2, 1), torch.zeros(2, 3), torch.ones(2))
+
+
+def test_product_never_imports_the_oracle():
+    from conftest import ROOT
+
+    for p in (ROOT / "mkb_amd").rglob("*.py"):
+        src = p.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), p
+
+
+def test_model_init_matches_reference_doctests(golden):
+    from mkb_amd import datasets, models
+
+    g = golden("init.npz")
+    ds = datasets.CountriesS1(batch_size=2, seed=42)
+    assert (ds.n_entity, ds.n_relation, len(ds.train), len(ds.valid), len(ds.test)) == (271, 2, 1111, 24, 24)
+    for name in ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"]:
+        torch.manual_seed(42)
+        m = getattr(models, name)(hidden_dim=3, entities=ds.entities, relations=ds.relations, gamma=1)
+        np.testing.assert_array_equal(m.entity_embedding.detach().numpy(), g[f"{name}/ent"])
+        np.testing.assert_array_equal(m.relation_embedding.detach().numpy(), g[f"{name}/rel"])
+        np.testing.assert_array_equal(m.embeddings["entities"]["oceania"].numpy(), g[f"{name}/oceania"])
+        assert repr(m) == bytes(g[f"{name}/repr"]).decode()
+
+
+def test_dataset_sizes_match_reference_doctests():
+    """datasets/{umls,fb15k237,wn18rr}.py:39-57."""
+    from mkb_amd import datasets
+
+    for cls, want in [("Umls", (135, 46, 5216, 652, 661)), ("Fb15k237", (14541, 237, 272115, 17535, 20466)),
+                      ("Wn18rr", (40943, 11, 86835, 3034, 3134))]:
+        ds = getattr(datasets, cls)(batch_size=1, shuffle=False, seed=42, num_workers=0)
+        assert (ds.n_entity, ds.n_relation, len(ds.train), len(ds.valid), len(ds.test)) == want
+
+
+def test_train_batches_and_weights_match_reference(golden):
+    from mkb_amd import datasets
+
+    g = golden("weights.npz")
+    for cls in ["Umls", "Fb15k237"]:
+        ds = getattr(datasets, cls)(batch_size=256, shuffle=False, seed=42, num_workers=0)
+        np.testing.assert_array_equal(ds.dataset_head.dataset.weights.numpy(), g[f"{cls}/weights"])
+    ds = datasets.Umls(batch_size=256, shuffle=False, seed=42, num_workers=0)
+    for i, data in enumerate(ds):
+        if i == 4:
+            break
+        np.testing.assert_array_equal(data["sample"].numpy(), g[f"Umls/batch{i}/sample"])
+        np.testing.assert_array_equal(data["weight"].numpy(), g[f"Umls/batch{i}/weight"])
+        assert data["mode"] == bytes(g[f"Umls/batch{i}/mode"]).decode()
+    ds = datasets.Umls(batch_size=256, shuffle=True, seed=42, num_workers=0)  # torch RandomSampler order
+    for i, data in enumerate(ds):
+        if i == 2:
+            break
+        np.testing.assert_array_equal(data["sample"].numpy(), g[f"Umls/shuffled{i}/sample"])
+
+
+def test_sampler_csr_equals_oracle_dicts():
+    from mkb_amd import datasets, sampling
+    from oracle import sampler as osamp
+
+    ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    th, tt = sampling.positive_triples(ds.train)
+    oh, ot = osamp.positive_triples(ds.train)
+    assert set(th) == set(oh) and set(tt) == set(ot)
+    for k in oh:
+        np.testing.assert_array_equal(th[k], oh[k])
+    for k in ot:
+        np.testing.assert_array_equal(tt[k], ot[k])
+
+
+def test_test_dataset_items():
+    """datasets/base.py:196-251: candidate ids / filter bias of TestDataset and TestDatasetRelation."""
+    from mkb_amd.datasets import TestDataset, TestDatasetRelation
+
+    ents, rels = {i: i for i in range(5)}, {0: 0, 1: 1}
+    true = [(0, 0, 1), (2, 0, 1), (0, 0, 3), (0, 1, 1)]
+    s, n, b, mode = TestDataset([(0, 0, 1)], true, ents, rels, "head-batch")[0]
+    assert s.tolist() == [0, 0, 1] and mode == "head-batch"
+    assert n.tolist() == [0, 1, 0, 3, 4] and b.tolist() == [0, 0, -100000.0, 0, 0]   # (2,0,1) is another true triple
+    s, n, b, _ = TestDataset([(0, 0, 1)], true, ents, rels, "tail-batch")[0]
+    assert n.tolist() == [0, 1, 2, 1, 4] and b.tolist() == [0, 0, 0, -100000.0, 0]   # (0,0,3)
+    s, n, b, mode = TestDatasetRelation([(0, 0, 1)], true, ents, rels)[0]
+    assert mode == "relation-batch" and n.tolist() == [[0, 0, 1], [0, 0, 1]] and b.tolist() == [0, -1]
