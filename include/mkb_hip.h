@@ -148,6 +148,24 @@ int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
              int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream);
 
+/* ---- per-kernel timing (measurement aid, no reference counterpart) -------------------------------------
+ * When enabled, the launches of the named kernel class are bracketed by hipEvents recorded on the SAME stream
+ * the kernel is launched on.  mkb_profile_read synchronises, returns the number of bracketed launches and
+ * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward,
+ * 1 = pooled forward, 2 = dense Adam, 3 = sampler (draw + filter), 4 = adversarial loss, 5 = general forward,
+ * 6 = general backward.  At most 8192 launches are kept between reads.
+ */
+#define MKB_PROF_POOL_BWD 0
+#define MKB_PROF_POOL_FWD 1
+#define MKB_PROF_ADAM 2
+#define MKB_PROF_SAMPLER 3
+#define MKB_PROF_LOSS 4
+#define MKB_PROF_GENERAL_FWD 5
+#define MKB_PROF_GENERAL_BWD 6
+#define MKB_PROF_KINDS 7
+int mkb_profile_enable(int kernel, int on);
+int mkb_profile_read(int kernel, int64_t *launches, double *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,10 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 import torch
 
-_LIB_PATH = pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"
+import os
+
+# MKB_HIP_LIB selects an experimental build of the same ABI (tools/kbench.py); default = the in-tree product library
+_LIB_PATH = pathlib.Path(os.environ.get("MKB_HIP_LIB") or (pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"))
 ABI_VERSION = 1
 
 MODEL_IDS = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}
@@ -64,6 +67,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     "mkb_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
                               c_float, c_int, c_void_p]),
+    "mkb_profile_enable": (c_int, [c_int, c_int]),
+    "mkb_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double)]),
     "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                          c_void_p]),
 }
@@ -87,6 +92,20 @@ def lib():
             raise HipLibraryError(f"ABI version mismatch: library {handle.mkb_abi_version()}, binding {ABI_VERSION}")
         _lib = handle
     return _lib
+
+
+PROF_KINDS = {"pool_bwd": 0, "pool_fwd": 1, "adam": 2, "sampler": 3, "loss": 4, "general_fwd": 5, "general_bwd": 6}
+
+
+def profile_enable(kind, on=True):
+    check(lib().mkb_profile_enable(PROF_KINDS[kind], int(on)), "mkb_profile_enable")
+
+
+def profile_read(kind):
+    """-> (launches, total_ms) of the bracketed launches since the last read (synchronises)."""
+    n, ms = c_int64(), ctypes.c_double()
+    check(lib().mkb_profile_read(PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms)), "mkb_profile_read")
+    return n.value, ms.value
 
 
 def check(rc, what):

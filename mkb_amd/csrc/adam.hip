@@ -68,6 +68,7 @@ extern "C" int mkb_adam_step(float *param, float *grad, float *exp_avg, float *e
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
+    mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
     hipLaunchKernelGGL(mkb::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, w1, beta2, w2, neg_step, sqrt_bc2, eps, zero_grad);
     MKB_LAUNCH_CHECK();

@@ -29,13 +29,26 @@ def _needs(src, obj):
     return obj.stat().st_mtime < newest
 
 
-def build(force=False, save_temps=False, verbose=True):
+def build(force=False, save_temps=False, verbose=True, extra_flags=(), out=None, objdir=None):
+    """extra_flags / out / objdir build an experimental variant (tools/kbench.py) next to the product library."""
+    global OBJ
+    out = OUT if out is None else pathlib.Path(out)
+    saved_obj = OBJ
+    if objdir is not None:
+        OBJ = pathlib.Path(objdir)
+    try:
+        return _build(force, save_temps, verbose, tuple(extra_flags), out)
+    finally:
+        OBJ = saved_obj
+
+
+def _build(force, save_temps, verbose, extra_flags, OUT):
     OBJ.mkdir(exist_ok=True)
     jobs = []
     for src in sources():
         obj = OBJ / (src.stem + ".o")
         if force or _needs(src, obj):
-            cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+            cmd = [HIPCC, *FLAGS, *extra_flags, "-c", str(src), "-o", str(obj)]
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
             jobs.append(cmd)

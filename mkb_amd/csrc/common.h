@@ -44,4 +44,14 @@ inline int validate_tables(const mkb_tables_t *tb) {
 
 inline bool mode_is_head(int mode) { return mode == MKB_MODE_HEAD; }
 
+// Brackets a kernel launch with hipEvents on the launch stream when profiling of `kind` is enabled
+// (mkb_profile_enable).  Usage:  { ProfScope ps(MKB_PROF_ADAM, st); hipLaunchKernelGGL(...); }
+struct ProfScope {
+    int kind;
+    hipStream_t st;
+    int slot;
+    ProfScope(int kind, hipStream_t st);
+    ~ProfScope();
+};
+
 }  // namespace mkb

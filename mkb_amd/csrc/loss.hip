@@ -107,6 +107,7 @@ extern "C" int mkb_adversarial(const float *pos, const float *neg, const float *
     MKB_REQUIRE(B > 0 && K > 0 && B <= INT32_MAX && K <= INT32_MAX, "bad B / K");
     hipStream_t st = (hipStream_t)stream;
     float *scal = scratch, *rowpart = scratch + 1;
+    ProfScope ps(MKB_PROF_LOSS, st);
     hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
     hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
                        (int)B, (int)K, alpha, scal, dpos, dneg, rowpart);

@@ -349,6 +349,7 @@ extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int
     MKB_REQUIRE(B >= 0 && B <= INT32_MAX, "bad B");
     hipStream_t st = (hipStream_t)stream;
     const int P = (int)(2 * s->K);
+    ProfScope ps(MKB_PROF_SAMPLER, st);
     hipLaunchKernelGGL(pool_draw_kernel, dim3(1), dim3(1024), 0, st, s->mt, s->mtpos, (uint32_t)(s->n_entity - 1), P,
                        s->pool, pool, s->lastflag);
     MKB_LAUNCH_CHECK();

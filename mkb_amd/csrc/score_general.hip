@@ -162,6 +162,7 @@ template <int MODEL>
 static int launch_fwd(const TablesDev &T, const int64_t *sample, const int64_t *cand, int64_t B, int K, bool head,
                       float *score, hipStream_t st) {
     const size_t lds = (size_t)T.De * sizeof(float);
+    ProfScope ps(MKB_PROF_GENERAL_FWD, st);
     if (head)
         hipLaunchKernelGGL((score_fwd_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), lds, st, T, sample, cand, K, score);
     else
@@ -173,6 +174,7 @@ static int launch_fwd(const TablesDev &T, const int64_t *sample, const int64_t *
 template <int MODEL>
 static int launch_bwd(const TablesDev &T, const mkb_grads_t &G, const int64_t *sample, const int64_t *cand, int64_t B,
                       int K, bool head, const float *dscore, hipStream_t st) {
+    ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     if (head)
         hipLaunchKernelGGL((score_bwd_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
     else
