@@ -69,10 +69,12 @@ def run_step(ctx, i):
     sample = ctx["train"][idx]
     weight = ctx["weights"][idx]
     mode = "head-batch" if i % 2 == 0 else "tail-batch"
+    ex = ctx["exchange"]
+    wsum = ex.weight_sum(weight) if ex is not None else None   # global-batch normaliser (all-reduced scalar)
     neg = ctx["sampler"].generate(sample, mode)
-    loss = ctx["step"](sample, weight, neg, mode)
-    if ctx["exchange"] is not None:
-        ctx["exchange"](sample, neg, mode)
+    loss = ctx["step"](sample, weight, neg, mode, weight_sum=wsum)
+    if ex is not None:
+        ex(sample, neg)                                           # sparse all-reduce of the touched gradient rows
     ctx["opt"].step()
     ctx["opt"].zero_grad()
     return loss
@@ -147,7 +149,7 @@ def main():
     if world > 1:
         from mkb_amd import parallel
 
-        ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], B, K)
+        ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], equal_batches=True)
 
     def barrier():
         torch.cuda.synchronize()

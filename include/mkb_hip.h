@@ -83,15 +83,18 @@ int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *
  * per-column multiplicity (null = all ones) used by the pooled path, where a column is a pool position.
  * scratch: B+1 floats of caller-owned device memory (W and the per-row partial sums; the reduction is a
  * fixed tree, so the loss is bit-reproducible run to run).
+ * weight_sum: null, or a device scalar holding W when the rows are a SHARD of a larger batch (data-parallel
+ * ranks pass the all-reduced sum of weights; loss then is this shard's share of the global loss).
  */
 int mkb_adversarial(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B,
-                    int64_t K, float alpha, float *loss, float *dpos, float *dneg, float *scratch, void *stream);
+                    int64_t K, float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg,
+                    float *scratch, void *stream);
 
 /* ---- negative sampler --------------------------------------------------------------------------------
  * mkb_sampler_create == sampling.NegativeSampling.__init__ (negative_sampling.py:133-151): takes the two
  *   filter dictionaries of positive_triples() (negative_sampling.py:7-28) as CSR on the HOST:
  *   keys sorted ascending (head filter: r*n_entity+t -> heads; tail filter: h*n_relation+r -> tails),
- *   offsets [nk+1], values sorted ascending within each set.  Copies them to the device.
+ *   offsets [nk+1], values sorted ascending within each set.  Copies them to the device.  K <= 1024.
  * mkb_sampler_generate == NegativeSampling.generate(sample, mode) (negative_sampling.py:158-201), bit-exact
  *   with numpy's legacy MT19937 randint + np.in1d(assume_unique=True, invert=True) of numpy >= 1.24:
  *   neg [B,K] int64 out; optional outs for the pooled scoring path: pool [2K] int64 (the shared candidate
@@ -116,12 +119,13 @@ void mkb_sampler_destroy(mkb_sampler_t *s);
  * (negative_sampling.py:166): positive forward (mode None), negative forward (mode), Adversarial,
  * backward into the dense gradient buffers.  Uses pool/cnt from mkb_sampler_generate.
  *   ws: workspace of mkb_pool_step_workspace_bytes() bytes; pos_score [B] out, pool_score [B,2K] out
- *   (score of row i against pool position p, valid where cnt>0), loss [1] out.
+ *   (score of row i against pool position p, valid where cnt>0), loss [1] out; weight_sum as in
+ *   mkb_adversarial (null = sum of this call's weights).
  */
 int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K);
 int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                   const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
-                  float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
+                  const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
 /* pooled model.forward / its autograd as separate calls (README-style loops that call the model and the loss
  * themselves): pool_score [B,2K] out; dpool_score [B,2K] = d loss / d pool_score in. */
 int mkb_pool_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "mkb_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                               c_void_p]),
     "mkb_adversarial": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_sampler_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_uint32, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_sampler_generate": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -60,7 +60,7 @@ _SIGNATURES = {
     "mkb_sampler_destroy": (None, [c_void_p]),
     "mkb_pool_step_workspace_bytes": (c_int64, [POINTER(Tables), c_int64, c_int64]),
     "mkb_pool_step": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                              c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                              c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_pool_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p]),
     "mkb_pool_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,

@@ -101,14 +101,15 @@ __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__
 using namespace mkb;
 
 extern "C" int mkb_adversarial(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B,
-                               int64_t K, float alpha, float *loss, float *dpos, float *dneg, float *scratch,
-                               void *stream) {
+                               int64_t K, float alpha, const float *weight_sum, float *loss, float *dpos,
+                               float *dneg, float *scratch, void *stream) {
     MKB_REQUIRE(pos && neg && weight && loss && dpos && dneg && scratch, "null pointer");
     MKB_REQUIRE(B > 0 && K > 0 && B <= INT32_MAX && K <= INT32_MAX, "bad B / K");
     hipStream_t st = (hipStream_t)stream;
     float *scal = scratch, *rowpart = scratch + 1;
     ProfScope ps(MKB_PROF_LOSS, st);
-    hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
+    if (weight_sum) scal = const_cast<float *>(weight_sum);  // W of the whole (sharded) batch, supplied by the caller
+    else hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
     hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
                        (int)B, (int)K, alpha, scal, dpos, dneg, rowpart);
     hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B, scal, loss);

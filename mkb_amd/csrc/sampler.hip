@@ -32,8 +32,16 @@ constexpr int MT_N = 624, MT_M = 397;
 struct Csr {
     int64_t *keys = nullptr, *offsets = nullptr, *values = nullptr;
     uint8_t *sortflag = nullptr;
+    int32_t *htab = nullptr;  // open-addressing hash: slot -> key index or -1 (capacity = pow2 >= 2 nk)
+    uint32_t hmask = 0;
     int64_t nk = 0;
 };
+
+__host__ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
 
 }  // namespace mkb
 
@@ -44,6 +52,7 @@ struct mkb_sampler {
     int32_t *status;   // device [2]: code, row
     int64_t *pool;     // device [2K] (internal copy when the caller passes none)
     uint8_t *lastflag; // device [2K]
+    int32_t *sorted_val, *sorted_pos;  // device [P2]: the pool sorted by (entity, position), P2 = pow2 >= 2K
     mkb::Csr head, tail;
 };
 
@@ -81,8 +90,11 @@ __device__ __forceinline__ int block_scan_flag(bool flag, int *wave_tot, int *to
 }
 
 __global__ __launch_bounds__(1024) void pool_draw_kernel(uint32_t *__restrict__ mt_g, int32_t *__restrict__ pos_g,
-                                                         uint32_t rng, int P, int64_t *__restrict__ pool,
-                                                         int64_t *__restrict__ pool2, uint8_t *__restrict__ lastflag) {
+                                                         uint32_t rng, int P, int P2_arg, int64_t *__restrict__ pool,
+                                                         int64_t *__restrict__ pool2, uint8_t *__restrict__ lastflag,
+                                                         int32_t *__restrict__ sorted_val, int32_t *__restrict__ sorted_pos) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skey[];  // [P2] sort keys, then...
+    uint32_t *pool_out_l = reinterpret_cast<uint32_t *>(skey + P2_arg);          // [P] drawn values
     __shared__ uint32_t mt[MT_N];
     __shared__ int wave_tot[16];
     __shared__ int s_newpos;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(1024) void pool_draw_kernel(uint32_t *__restrict__ 
     __syncthreads();
     int have = 0;
     if (rng == 0) {  // randint(1): no stream consumption
-        for (int p = tid; p < P; p += 1024) { pool[p] = 0; if (pool2) pool2[p] = 0; }
+        for (int p = tid; p < P; p += 1024) { pool[p] = 0; if (pool2) pool2[p] = 0; pool_out_l[p] = 0; }
         have = P;
     }
     while (have < P) {
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(1024) void pool_draw_kernel(uint32_t *__restrict__ 
         if (acc && rank < need) {
             pool[have + rank] = (int64_t)v;
             if (pool2) pool2[have + rank] = (int64_t)v;
+            pool_out_l[have + rank] = v;
         }
         if (tid == 0) s_newpos = MT_N;
         __syncthreads();
@@ -140,17 +153,40 @@ __global__ __launch_bounds__(1024) void pool_draw_kernel(uint32_t *__restrict__ 
     }
     if (tid < MT_N) mt_g[tid] = mt[tid];
     if (tid == 0) pos_g[0] = pos;
-    // lastflag[p] = no later pool position holds the same entity (the np.in1d sort path keeps only those)
-    __threadfence_block();
     __syncthreads();
-    for (int p = tid; p < P; p += 1024) {
-        const int64_t c = pool[p];
-        uint8_t last = 1;
-        for (int q = p + 1; q < P; ++q)
-            if (pool[q] == c) { last = 0; break; }
-        lastflag[p] = last;
+    // ---- per-batch helpers for the row filter, all in LDS ------------------------------------------------
+    // keys[e] = entity << 13 | position, sorted ascending (bitonic): equal entities are adjacent, positions ascending
+    const int P2 = P2_arg;
+    for (int e = tid; e < P2; e += 1024)
+        skey[e] = e < P ? (((unsigned long long)(pool_out_l[e])) << 13) | (unsigned)e : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = tid; e < P2; e += 1024) {
+                const int partner = e ^ j;
+                if (partner > e) {
+                    const unsigned long long a = skey[e], b = skey[partner];
+                    const bool up = (e & k) == 0;
+                    if ((a > b) == up) { skey[e] = b; skey[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < P2; e += 1024) {
+        const unsigned long long kk = skey[e];
+        const bool real = kk != ~0ull;
+        sorted_val[e] = real ? (int32_t)(kk >> 13) : INT32_MAX;
+        sorted_pos[e] = real ? (int32_t)(kk & 8191u) : -1;
+        // lastflag[p]: no later position holds the same entity == next sorted key has a different entity
+        if (real) {
+            const unsigned long long nx = (e + 1 < P2) ? skey[e + 1] : ~0ull;
+            lastflag[kk & 8191u] = (nx == ~0ull || (nx >> 13) != (kk >> 13)) ? 1 : 0;
+        }
     }
 }
+
+__device__ __forceinline__ uint32_t bloom_hash(int32_t v) { return (uint32_t)v * 2654435761u >> 7; }
 
 __device__ __forceinline__ int64_t lower_bound_dev(const int64_t *__restrict__ a, int64_t n, int64_t v) {
     int64_t lo = 0, hi = n;
@@ -161,42 +197,98 @@ __device__ __forceinline__ int64_t lower_bound_dev(const int64_t *__restrict__ a
     return lo;
 }
 
-// one wave per row, 4 rows per workgroup; dynamic LDS: per wave P int32 kept positions + P int32 ranks
+// one wave per row, 4 rows per workgroup.  Dynamic LDS: the sorted pool (P2 values + P2 positions, shared by the
+// 4 waves) and per wave P kept positions + P ranks + P/32 membership words.
+// Membership is searched the cheap way round: the row's true set streams from global memory with coalesced
+// loads and each element is binary-searched in the SORTED POOL held in LDS (m log P LDS steps), instead of
+// binary-searching global memory for each of the P candidates (P log m dependent global loads).
 __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restrict__ sample, int B, int head_mode,
-                                                          int64_t key_stride, const int64_t *__restrict__ keys, int64_t nk,
-                                                          const int64_t *__restrict__ offsets,
-                                                          const int64_t *__restrict__ values,
-                                                          const uint8_t *__restrict__ sortflag,
+                                                          int64_t key_stride, Csr csr,
                                                           const int64_t *__restrict__ pool,
-                                                          const uint8_t *__restrict__ lastflag, int K, int P,
-                                                          int64_t *__restrict__ neg, int32_t *__restrict__ posmap,
+                                                          const uint8_t *__restrict__ lastflag,
+                                                          const int32_t *__restrict__ sorted_val,
+                                                          const int32_t *__restrict__ sorted_pos, int K, int P, int P2,
+                                                          int rows_per_wg, int64_t *__restrict__ neg, int32_t *__restrict__ posmap,
                                                           uint16_t *__restrict__ cnt, int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_i32[];
+    int32_t *sval = lds_i32, *spos = lds_i32 + P2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
-    const bool valid = i < B;
-    int32_t *kept = lds_i32 + (size_t)wave * 2 * P;  // kept[rho] = pool position of the rho-th surviving candidate
-    int32_t *rank = kept + P;                        // rank[p]   = rho, or -1 when position p is filtered out
+    const int words = (P + 31) / 32;
+    const int wslot = wave < rows_per_wg ? wave : 0;  // idle waves alias slot 0 but never touch it
+    int32_t *kept = lds_i32 + 2 * P2 + (size_t)wslot * (2 * P + words);  // kept[rho] = position of the rho-th survivor
+    int32_t *rank = kept + P;                                            // rank[p] = rho or -1
+    uint32_t *member = reinterpret_cast<uint32_t *>(rank + P);           // bit p: pool[p] is in the row's true set
+    // Bloom bitmap of the pool's entity ids: 32 bits per pool slot (P2 words), one hash
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(lds_i32 + 2 * P2 + (size_t)rows_per_wg * (2 * P + words));
+    const uint32_t bloom_mask = (uint32_t)P2 * 32u - 1u;
+    for (int e = threadIdx.x; e < P2; e += 256) { sval[e] = sorted_val[e]; spos[e] = sorted_pos[e]; bloom[e] = 0; }
+    if (wave < rows_per_wg) for (int w = lane; w < words; w += 64) member[w] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < P2; e += 256) {
+        if (spos[e] >= 0) {
+            const uint32_t hb = bloom_hash(sval[e]) & bloom_mask;
+            atomicOr(&bloom[hb >> 5], 1u << (hb & 31));
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * rows_per_wg + wave;
+    const bool valid = wave < rows_per_wg && i < B;
     bool found = false;
     int nf = 0;
     if (valid) {
         const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
         const int64_t key = head_mode ? r * key_stride + t : h * key_stride + r;
-        const int64_t ki = lower_bound_dev(keys, nk, key);
-        found = ki < nk && keys[ki] == key;
+        int64_t ki = -1;
+        if (csr.nk > 0) {
+            uint32_t slot = (uint32_t)mix64((uint64_t)key) & csr.hmask;
+            for (;;) {
+                const int32_t idx = csr.htab[slot];
+                if (idx < 0) break;
+                if (csr.keys[idx] == key) { ki = idx; break; }
+                slot = (slot + 1) & csr.hmask;
+            }
+        }
+        found = ki >= 0;
         if (found) {
-            const int64_t off = offsets[ki];
-            const int64_t m = offsets[ki + 1] - off;
-            const int64_t *rec = values + off;
-            const bool sortpath = sortflag[ki] != 0;
+            const int64_t off = csr.offsets[ki];
+            const int m = (int)(csr.offsets[ki + 1] - off);
+            const int64_t *rec = csr.values + off;
+            const bool sortpath = csr.sortflag[ki] != 0;
+            // Stream the true set 8 elements per lane at a time (independent coalesced loads in flight together),
+            // probe a Bloom bitmap of the pool first: almost every element misses and costs one LDS read; the
+            // rare hit is confirmed (and its positions found) by binary search in the sorted pool.
+            for (int e0 = 0; e0 < m; e0 += 64 * 8) {
+                int64_t v64[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    v64[u] = e < m ? rec[e] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (v64[u] < 0 || v64[u] >= INT32_MAX) continue;
+                    const int32_t v = (int32_t)v64[u];
+                    const uint32_t hb = bloom_hash(v) & bloom_mask;
+                    if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) continue;
+                    int lo = 0, hi = P2;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (sval[mid] < v) lo = mid + 1; else hi = mid;
+                    }
+                    for (; lo < P2 && sval[lo] == v; ++lo) {
+                        const int p = spos[lo];
+                        atomicOr(&member[p >> 5], 1u << (p & 31));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             for (int base = 0; base < P; base += 64) {
                 const int p = base + lane;
                 bool keep = false;
                 if (p < P) {
-                    const int64_t c = pool[p];
-                    const int64_t j = lower_bound_dev(rec, m, c);
-                    const bool member = j < m && rec[j] == c;
-                    keep = !member && (!sortpath || lastflag[p] != 0);
+                    const bool mem = (member[p >> 5] >> (p & 31)) & 1u;
+                    keep = !mem && (!sortpath || lastflag[p] != 0);
                 }
                 const unsigned long long b = __ballot(keep);
                 const int rho = nf + __popcll(b & ((1ull << lane) - 1ull));
@@ -235,7 +327,7 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
 
 static int upload_csr(Csr &c, const int64_t *keys, int64_t nk, const int64_t *offsets, const int64_t *values, int64_t P,
                       hipStream_t st) {
-    MKB_REQUIRE(nk >= 0 && (nk == 0 || (keys && offsets && values)), "bad CSR");
+    MKB_REQUIRE(nk >= 0 && nk < (1ll << 30) && (nk == 0 || (keys && offsets && values)), "bad CSR");
     c.nk = nk;
     const int64_t nv = nk ? offsets[nk] : 0;
     std::vector<uint8_t> flag((size_t)(nk ? nk : 1), 0);
@@ -252,6 +344,17 @@ static int upload_csr(Csr &c, const int64_t *keys, int64_t nk, const int64_t *of
     MKB_CHECK_HIP(hipMalloc(&c.offsets, sizeof(int64_t) * (size_t)(nk + 1)));
     MKB_CHECK_HIP(hipMalloc(&c.values, sizeof(int64_t) * (size_t)(nv ? nv : 1)));
     MKB_CHECK_HIP(hipMalloc(&c.sortflag, (size_t)(nk ? nk : 1)));
+    uint32_t cap = 2;
+    while ((int64_t)cap < 2 * nk) cap <<= 1;
+    std::vector<int32_t> htab(cap, -1);
+    c.hmask = cap - 1;
+    for (int64_t k = 0; k < nk; ++k) {
+        uint32_t slot = (uint32_t)mix64((uint64_t)keys[k]) & c.hmask;
+        while (htab[slot] >= 0) slot = (slot + 1) & c.hmask;
+        htab[slot] = (int32_t)k;
+    }
+    MKB_CHECK_HIP(hipMalloc(&c.htab, sizeof(int32_t) * cap));
+    MKB_CHECK_HIP(hipMemcpyAsync(c.htab, htab.data(), sizeof(int32_t) * cap, hipMemcpyHostToDevice, st));
     if (nk) {
         MKB_CHECK_HIP(hipMemcpyAsync(c.keys, keys, sizeof(int64_t) * (size_t)nk, hipMemcpyHostToDevice, st));
         MKB_CHECK_HIP(hipMemcpyAsync(c.offsets, offsets, sizeof(int64_t) * (size_t)(nk + 1), hipMemcpyHostToDevice, st));
@@ -263,7 +366,7 @@ static int upload_csr(Csr &c, const int64_t *keys, int64_t nk, const int64_t *of
 }
 
 static void free_csr(Csr &c) {
-    (void)hipFree(c.keys); (void)hipFree(c.offsets); (void)hipFree(c.values); (void)hipFree(c.sortflag);
+    (void)hipFree(c.keys); (void)hipFree(c.offsets); (void)hipFree(c.values); (void)hipFree(c.sortflag); (void)hipFree(c.htab);
     c = Csr();
 }
 
@@ -276,17 +379,22 @@ extern "C" int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t
                                   const int64_t *head_values_host, const int64_t *tail_keys_host, int64_t n_tail_keys,
                                   const int64_t *tail_offsets_host, const int64_t *tail_values_host, void *stream) {
     MKB_REQUIRE(out != nullptr, "out is null");
-    MKB_REQUIRE(n_entity > 0 && n_entity <= 0xFFFFFFFFll && n_relation > 0, "bad n_entity / n_relation");
-    MKB_REQUIRE(K > 0 && 2 * K <= 8192, "size must be in [1, 4096]");
+    MKB_REQUIRE(n_entity > 0 && n_entity < INT32_MAX && n_relation > 0, "bad n_entity / n_relation");
+    MKB_REQUIRE(K > 0 && K <= 1024, "size must be in [1, 1024] for the device sampler");
     hipStream_t st = (hipStream_t)stream;
     mkb_sampler *s = new mkb_sampler();
     s->n_entity = n_entity; s->n_relation = n_relation; s->K = K;
     s->mt = nullptr; s->mtpos = nullptr; s->status = nullptr; s->pool = nullptr; s->lastflag = nullptr;
+    s->sorted_val = nullptr; s->sorted_pos = nullptr;
+    int P2 = 2;
+    while (P2 < 2 * K) P2 <<= 1;
     auto fail = [&](int rc) { mkb_sampler_destroy(s); return rc; };
     if (hipMalloc(&s->mt, sizeof(uint32_t) * MT_N) != hipSuccess || hipMalloc(&s->mtpos, sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&s->status, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&s->pool, sizeof(int64_t) * (size_t)(2 * K)) != hipSuccess ||
-        hipMalloc(&s->lastflag, (size_t)(2 * K)) != hipSuccess)
+        hipMalloc(&s->lastflag, (size_t)(2 * K)) != hipSuccess ||
+        hipMalloc(&s->sorted_val, sizeof(int32_t) * (size_t)P2) != hipSuccess ||
+        hipMalloc(&s->sorted_pos, sizeof(int32_t) * (size_t)P2) != hipSuccess)
         return fail(set_error(MKB_ERR_HIP, "hipMalloc failed in mkb_sampler_create"));
     uint32_t key[MT_N];
     uint32_t sd = seed;  // numpy mt19937_seed == init_genrand
@@ -304,6 +412,7 @@ extern "C" int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t
 extern "C" void mkb_sampler_destroy(mkb_sampler_t *s) {
     if (!s) return;
     (void)hipFree(s->mt); (void)hipFree(s->mtpos); (void)hipFree(s->status); (void)hipFree(s->pool); (void)hipFree(s->lastflag);
+    (void)hipFree(s->sorted_val); (void)hipFree(s->sorted_pos);
     free_csr(s->head);
     free_csr(s->tail);
     delete s;
@@ -349,17 +458,21 @@ extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int
     MKB_REQUIRE(B >= 0 && B <= INT32_MAX, "bad B");
     hipStream_t st = (hipStream_t)stream;
     const int P = (int)(2 * s->K);
+    int P2 = 2;
+    while (P2 < P) P2 <<= 1;
     ProfScope ps(MKB_PROF_SAMPLER, st);
-    hipLaunchKernelGGL(pool_draw_kernel, dim3(1), dim3(1024), 0, st, s->mt, s->mtpos, (uint32_t)(s->n_entity - 1), P,
-                       s->pool, pool, s->lastflag);
+    hipLaunchKernelGGL(pool_draw_kernel, dim3(1), dim3(1024), (size_t)P2 * 8 + (size_t)P * 4, st, s->mt, s->mtpos,
+                       (uint32_t)(s->n_entity - 1), P, P2, s->pool, pool, s->lastflag, s->sorted_val, s->sorted_pos);
     MKB_LAUNCH_CHECK();
     if (B == 0) return MKB_OK;
     const bool head = mode == MKB_MODE_HEAD;
     const Csr &c = head ? s->head : s->tail;
     const int64_t stride = head ? s->n_entity : s->n_relation;
-    hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)8 * P * sizeof(int32_t), st,
-                       sample, (int)B, head ? 1 : 0, stride, c.keys, c.nk, c.offsets, c.values, c.sortflag, s->pool,
-                       s->lastflag, (int)s->K, P, neg, pos, cnt, s->status);
+    const int rw = P <= 1024 ? 4 : 1;  // rows (waves) per workgroup: keeps the LDS request under 64 KB up to P = 2048
+    const size_t lds = sizeof(int32_t) * ((size_t)3 * P2 + (size_t)rw * ((size_t)2 * P + (P + 31) / 32));
+    hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)((B + rw - 1) / rw)), dim3(256), lds, st, sample, (int)B,
+                       head ? 1 : 0, stride, c, s->pool, s->lastflag, s->sorted_val, s->sorted_pos, (int)s->K, P, P2, rw,
+                       neg, pos, cnt, s->status);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

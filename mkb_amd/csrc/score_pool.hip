@@ -36,6 +36,10 @@ constexpr int kMaxP = 1024;        // pool positions supported by the LDS tile l
 constexpr int kFwdSlices = 2;      // position slices per row tile   (forward)
 constexpr int kBwdQSlices = 2;     // position slices per row tile   (backward, dq partial buffers)
 constexpr int kBwdXSlices = 6;     // row slices per position tile   (backward, dx partial buffers), minimum
+// The x pass launches more workgroups than CUs and many exit at once (position tiles nobody uses).  Two resident
+// workgroups on one CU while another CU idles doubled its run time; asking for > half of the 160 KB LDS admits
+// exactly one workgroup per CU, so the surplus is handed out as CUs free up.
+constexpr size_t kOnePerCuPad = 48 * 1024;
 
 struct PoolArgs {
     const float *ent;      // [N, De]
@@ -592,13 +596,13 @@ static int run_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t 
         ProfScope ps(MKB_PROF_POOL_BWD, st);
         if (NU <= kWG) {
             hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, 1>), gq, dim3(kWG), 0, st, A);
-            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 1>), gx, dim3(kWG), 0, st, A);
+            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 1>), gx, dim3(kWG), kOnePerCuPad, st, A);
         } else if (NU <= 2 * kWG) {
             hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, 2>), gq, dim3(kWG), 0, st, A);
-            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 2>), gx, dim3(kWG), 0, st, A);
+            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 2>), gx, dim3(kWG), kOnePerCuPad, st, A);
         } else {
             hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, 4>), gq, dim3(kWG), 0, st, A);
-            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 4>), gx, dim3(kWG), 0, st, A);
+            hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, 4>), gx, dim3(kWG), kOnePerCuPad, st, A);
         }
     }
     RowArgs ra{tb->ent, tb->rel, sample, w.dQ, gr->g_ent, gr->g_rel, tb->entity_dim, tb->relation_dim, tb->hidden_dim,
@@ -680,7 +684,8 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
 
 extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                              const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
-                             float *pos_score, float *pool_score, float *loss, void *ws, void *stream) {
+                             const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws,
+                             void *stream) {
     if (int rc = check_pool_call(tb, sample, pool, cnt, B, K, mode, ws)) return rc;
     MKB_REQUIRE(gr && gr->g_ent && gr->g_rel && weight && pos_score && pool_score && loss, "null pointer");
     MKB_REQUIRE(tb->model != MKB_PROTATE || gr->g_modulus, "pRotatE needs g_modulus");
@@ -693,7 +698,7 @@ extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, cons
     // negative pass over the shared pool (pipeline.py:230-232)
     if (int rc = dispatch_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, st)) return rc;
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
-    if (int rc = mkb_adversarial(pos_score, pool_score, weight, cnt, B, P, alpha, loss, w.dpos, w.G, w.scratch, stream)) return rc;
+    if (int rc = mkb_adversarial(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, stream)) return rc;
     // backward (pipeline.py:236): pooled negatives, then the positives through the general kernel
     if (int rc = dispatch_bwd(tb, head, gr, sample, pool, cnt, B, P, w, st)) return rc;
     return mkb_score_bwd(tb, gr, sample, nullptr, B, 1, MKB_MODE_DEFAULT, w.dpos, stream);

@@ -97,7 +97,9 @@ class FusedTrainStep:
         return _hip.Grads(m.entity_embedding.grad.data_ptr(), m.relation_embedding.grad.data_ptr(),
                           m.modulus.grad.data_ptr() if m.name == "pRotatE" else None)
 
-    def __call__(self, sample, weight, negative_sample, mode):
+    def __call__(self, sample, weight, negative_sample, mode, weight_sum=None):
+        """``weight_sum``: optional device scalar = sum of weights of the WHOLE batch when these rows are one
+        data-parallel shard of it (see mkb_amd.parallel); the returned loss is then this shard's share."""
         m = self.model
         info = getattr(negative_sample, "_mkb_pool", None)
         if info is None:
@@ -115,7 +117,8 @@ class FusedTrainStep:
         gr = self._grad_buffers()
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
-                                                _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(pos), _hip.ptr(S),
+                                                _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(weight_sum),
+                                                _hip.ptr(pos), _hip.ptr(S),
                                                 _hip.ptr(loss), _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_step")
         self.positive_score, self._S, self._info = pos, S, info
         return loss.reshape(())

@@ -23,7 +23,7 @@ class _AdversarialFn(torch.autograd.Function):
         scratch = torch.empty(B + 1, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_adversarial(_hip.ptr(pos), _hip.ptr(neg), _hip.ptr(weight), None, B, K, alpha,
-                                                  _hip.ptr(loss), _hip.ptr(dpos), _hip.ptr(dneg), _hip.ptr(scratch),
+                                                  None, _hip.ptr(loss), _hip.ptr(dpos), _hip.ptr(dneg), _hip.ptr(scratch),
                                                   _hip.stream_ptr()), "mkb_adversarial")
         ctx.save_for_backward(dpos, dneg)
         ctx.pos_shape = None

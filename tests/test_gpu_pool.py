@@ -187,3 +187,33 @@ def test_evaluation_countries_vs_reference(golden, name):
         want = gj[f"countries/{name}/{split}"]
         for k in want:
             assert abs(got[k] - want[k]) <= (0.1 if k == "MR" else 2e-3), (split, k, got, want)
+
+
+def test_sharded_batch_with_global_weight_sum_equals_full_batch():
+    """Data-parallel math on one GPU: two half-batches stepped with the GLOBAL normaliser W (weight_sum=) leave
+    the same dense gradients and total loss as one step over the whole batch (the sampler state is replayed so
+    both runs see the identical pool)."""
+    from mkb_amd.fused import FusedTrainStep
+
+    ds, m, tb, ns, train = _setup("Fb15k237", "RotatE", 32, 128, 64, gamma=9.0)
+    idx = torch.as_tensor(np.random.RandomState(3).randint(len(train), size=128))
+    s = train[idx].cuda()
+    w = (torch.rand(128) + 0.1).cuda()
+    step = FusedTrainStep(m, alpha=1.0)
+    ns.generate(s[:4], "tail-batch")                 # create the device handle
+    key, pos = ns.get_state()
+    neg = ns.generate(s, "tail-batch")
+    m.zero_grad(set_to_none=True)
+    full_loss = step(s, w, neg, "tail-batch").item()
+    g_full = (m.entity_embedding.grad.clone(), m.relation_embedding.grad.clone())
+    m.zero_grad(set_to_none=True)
+    W = w.sum().reshape(1)
+    total = 0.0
+    for lo, hi in ((0, 64), (64, 128)):              # "rank 0" and "rank 1": same RNG state -> same pool
+        ns.set_state(key, pos)
+        negh = ns.generate(s[lo:hi].contiguous(), "tail-batch")
+        np.testing.assert_array_equal(negh.cpu().numpy(), neg[lo:hi].cpu().numpy())
+        total += step(s[lo:hi].contiguous(), w[lo:hi].contiguous(), negh, "tail-batch", weight_sum=W).item()
+    np.testing.assert_allclose(total, full_loss, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), g_full[0].cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), g_full[1].cpu().numpy(), rtol=1e-4, atol=1e-6)
