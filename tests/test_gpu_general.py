@@ -96,7 +96,7 @@ def test_random_problem_vs_oracle(name, mode, shape):
     from util_gpu import make_model, oracle_tables, random_problem
 
     N, R, hid, B, K = shape
-    ent, rel, s, n, w, mod = random_problem(name, N, R, hid, B, K, seed=hash((name, mode, N)) % 1000)
+    ent, rel, s, n, w, mod = random_problem(name, N, R, hid, B, K, seed=MODELS.index(name) * 7 + len(mode) + N)
     m = make_model(name, ent, rel, hid, 6.0, mod)
     tb = oracle_tables(name, ent, rel, hid, 6.0, mod)
     ref = scoring.train_step_grads(tb, s, n, w, mode, 1.0, fast_norm=True)
@@ -110,9 +110,10 @@ def test_random_problem_vs_oracle(name, mode, shape):
                                 None if mod is None else mod.numpy())
     ge = m.entity_embedding.grad.cpu().numpy()
     gr = m.relation_embedding.grad.cpu().numpy()
-    np.testing.assert_allclose(ge, ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-    np.testing.assert_allclose(ge, c["g_ent"], rtol=0, atol=1e-5)
-    np.testing.assert_allclose(gr, c["g_rel"], rtol=1e-4, atol=1e-5)
+    tol = 1e-5 * max(1.0, float(np.abs(c["g_ent"]).max()))   # pRotatE / RotatE divide by range/pi ~ 1e-2
+    np.testing.assert_allclose(ge, ref["g_ent"].numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(ge, c["g_ent"], rtol=0, atol=tol)
+    np.testing.assert_allclose(gr, c["g_rel"], rtol=1e-4, atol=tol)
 
 
 def test_cpu_tensors_are_rejected():
