@@ -221,8 +221,14 @@ def main():
             what = (f"{prof_kind} kernel: logical bytes of the reference formulation ({passes} x B*K entity rows of "
                     f"{De * 4} B); the kernel itself is VALU-bound and reuses each pool row from registers")
         ach = alg / avg_s / 1e9
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(prof_kind, {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         roof = {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_kernel_us": avg_s * 1e6, "launches": launches,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg, "note": what}
     out = {
         "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000", "value": value, "unit": "triples/s",

@@ -31,15 +31,20 @@ namespace mkb {
 constexpr int kWG = 1024;          // lanes per workgroup (16 waves)
 constexpr int kWaves16 = kWG / 64;
 constexpr int TI = 8;              // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
+constexpr int kRing = 4;           // prefetch depth (positions / rows in flight per lane) of the streamed operand
 constexpr int kSlab = 16;          // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 1024;        // pool positions supported by the LDS tile lists
 constexpr int kFwdSlices = 2;      // position slices per row tile   (forward)
 constexpr int kBwdQSlices = 2;     // position slices per row tile   (backward, dq partial buffers)
-constexpr int kBwdXSlices = 6;     // row slices per position tile   (backward, dx partial buffers), minimum
-// The x pass launches more workgroups than CUs and many exit at once (position tiles nobody uses).  Two resident
-// workgroups on one CU while another CU idles doubled its run time; asking for > half of the 160 KB LDS admits
-// exactly one workgroup per CU, so the surplus is handed out as CUs free up.
+constexpr int kBwdXSlices = 8;     // row slices per position tile   (backward, dx partial buffers), minimum
+// x-pass occupancy knob (dynamic LDS request).  With 8 row slices and tile-major dispatch the 256 heavy workgroups
+// land one per CU and the light tiles co-run beside them; forcing one workgroup per CU (48 KB pad) measured 10 %
+// slower (241 vs 219 us for both backward passes), so no pad.
+#ifdef MKB_BWDX_PAD
 constexpr size_t kOnePerCuPad = 48 * 1024;
+#else
+constexpr size_t kOnePerCuPad = 0;
+#endif
 
 struct PoolArgs {
     const float *ent;      // [N, De]
@@ -52,7 +57,7 @@ struct PoolArgs {
     float *dX;             // [slices, P, De] (backward, x pass)
     float *g_modulus;      // pRotatE
     const float *modulus;  // pRotatE
-    int B, P, d;
+    int B, P, d, x_slices;
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 };
@@ -149,57 +154,80 @@ __global__ __launch_bounds__(kWG) void pool_fwd_kernel(PoolArgs A) {
     const int nsl = gridDim.y, sl = blockIdx.y;
     const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
 
-    float xn0[KPT], xn1[KPT];
-    auto load_x = [&](int j) {
+    // Candidate rows stream through a kRing-deep register ring: the first touch of a pool row by an XCD comes from
+    // Infinity Cache / HBM (~1 us), several positions' worth of compute, so one-ahead prefetch left every wave
+    // waiting on it (measured: loads cost 55 of 124 us).
+    float xr0[kRing][KPT], xr1[kRing][KPT];
+    auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
         const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
 #pragma unroll
-        for (int v = 0; v < KPT; ++v) {
-            const bool ok = u0 + v < NU;
-            xn0[v] = ok ? x[u0 + v] : 0.f;
-            xn1[v] = (CP && ok) ? x[A.d + u0 + v] : 0.f;
+        for (int v = 0; v < KPT; ++v) {  // unconditional loads from a clamped address + select: a predicated load
+            const bool ok = u0 + v < NU;  // becomes a branch whose join makes the compiler wait for it at once
+            const int uu = min(u0 + v, NU - 1);
+            const float l0 = x[uu];
+            const float l1 = CP ? x[A.d + uu] : 0.f;
+            d0[v] = ok ? l0 : 0.f;
+            d1[v] = ok ? l1 : 0.f;
         }
     };
-    if (n_mine > 0) load_x(0);
-    for (int j0 = 0; j0 < n_mine; j0 += kSlab) {
-        const int buf = (j0 / kSlab) & 1;
-        const int nb = min(kSlab, n_mine - j0);
-        for (int jj = 0; jj < nb; ++jj) {
-            const int j = j0 + jj;
-            const unsigned m = __builtin_amdgcn_readfirstlane(s_mask[sl + j * nsl]);
-            float x0[KPT], x1[KPT];
+    // Loads are UNCONDITIONAL (index clamped to the last position; the tail re-loads it) so that the compiler can
+    // count outstanding loads and wait with vmcnt(N) for the oldest only; a load under a branch forces vmcnt(0).
+    const int j_last = n_mine - 1;
+    if (n_mine > 0) {
 #pragma unroll
-            for (int v = 0; v < KPT; ++v) { x0[v] = xn0[v]; x1[v] = xn1[v]; }
-            if (j + 1 < n_mine) load_x(j + 1);  // next candidate row in flight while this one is scored
-            float part[TI];
+        for (int s = 0; s < kRing; ++s) load_x(min(s, j_last), xr0[s], xr1[s]);
+    }
+    for (int jb = 0; jb < n_mine; jb += kRing) {
 #pragma unroll
-            for (int r = 0; r < TI; ++r) {
-                part[r] = 0.f;
-                if (m & (1u << r)) {
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            {
+                const int jj = j % kSlab, buf = (j / kSlab) & 1;
+                const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[sl + min(j, j_last) * nsl]) : 0u;
+                float x0[KPT], x1[KPT];
 #pragma unroll
-                    for (int v = 0; v < KPT; ++v) {  // out-of-range units hold q = x = 0 and contribute exactly 0
-                        if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
-                        else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
+#ifndef MKB_ABL_NOLOAD
+                load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
+#endif
+                float part[TI];
+#pragma unroll
+                for (int r = 0; r < TI; ++r) {
+                    part[r] = 0.f;
+                    if (m & (1u << r)) {
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) {  // out-of-range units hold q = x = 0 and contribute exactly 0
+                            if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
+                            else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                        }
                     }
                 }
-            }
-            float t0, t1;
-            reduce8_wave(part, t0, t1);
-            if ((lane & 15) == 0) {
-                const int R = lane >> 4, r = 4 * (R >> 1) + 2 * (R & 1);
-                s_part[buf][jj][wave][r] = t0;
-                s_part[buf][jj][wave][r + 1] = t1;
-            }
-        }
-        __syncthreads();  // double-buffered: the next batch writes the other buffer, one barrier per batch
-        if (tid < nb * TI) {
-            const int jj = tid / TI, r = tid % TI;
-            const int a = sl + (j0 + jj) * nsl;
-            if (s_mask[a] & (1u << r)) {
-                float s = 0.f;
+                float t0, t1;
+#ifdef MKB_ABL_FWD_NOREDUCE
+                t0 = part[0] + part[1] + part[2] + part[3]; t1 = part[4] + part[5] + part[6] + part[7];
+#else
+                reduce8_wave(part, t0, t1);
+#endif
+                if ((lane & 15) == 0) {
+                    const int R = lane >> 4, r = 4 * (R >> 1) + 2 * (R & 1);
+                    s_part[buf][jj][wave][r] = t0;
+                    s_part[buf][jj][wave][r + 1] = t1;
+                }
+                if (j < n_mine && (jj == kSlab - 1 || j == j_last)) {  // wave-uniform: combine <= kSlab positions
+                    __syncthreads();  // double-buffered s_part: one barrier per batch
+                    const int j0 = j - jj, nb = jj + 1;
+                    if (tid < nb * TI) {
+                        const int cj = tid / TI, r = tid % TI;
+                        const int a = sl + (j0 + cj) * nsl;
+                        if (s_mask[a] & (1u << r)) {
+                            float sum = 0.f;
 #pragma unroll
-                for (int w = 0; w < kWaves16; ++w) s += s_part[buf][jj][w][r];
-                if constexpr (MODEL == MKB_PROTATE) s *= A.modulus[0];  // gamma - modulus * sum  (protate.py:91)
-                A.S[(int64_t)(i0 + r) * A.P + s_pos[a]] = A.c0 + A.c1 * s;
+                            for (int w = 0; w < kWaves16; ++w) sum += s_part[buf][cj][w][r];
+                            if constexpr (MODEL == MKB_PROTATE) sum *= A.modulus[0];  // gamma - modulus * sum (protate.py:91)
+                            A.S[(int64_t)(i0 + r) * A.P + s_pos[a]] = A.c0 + A.c1 * sum;
+                        }
+                    }
+                }
             }
         }
     }
@@ -260,42 +288,57 @@ __global__ __launch_bounds__(kWG) void pool_bwd_q_kernel(PoolArgs A) {
 
     const int nsl = gridDim.y, sl = blockIdx.y;
     const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
-    float xn0[KPT], xn1[KPT];
-    auto load_x = [&](int j) {
+    float xr0[kRing][KPT], xr1[kRing][KPT];
+    auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
         const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
 #pragma unroll
-        for (int v = 0; v < KPT; ++v) {
-            const bool ok = u0 + v < NU;
-            xn0[v] = ok ? x[u0 + v] : 0.f;
-            xn1[v] = (CP && ok) ? x[A.d + u0 + v] : 0.f;
+        for (int v = 0; v < KPT; ++v) {  // unconditional loads from a clamped address + select: a predicated load
+            const bool ok = u0 + v < NU;  // becomes a branch whose join makes the compiler wait for it at once
+            const int uu = min(u0 + v, NU - 1);
+            const float l0 = x[uu];
+            const float l1 = CP ? x[A.d + uu] : 0.f;
+            d0[v] = ok ? l0 : 0.f;
+            d1[v] = ok ? l1 : 0.f;
         }
     };
-    if (n_mine > 0) load_x(0);
-    for (int j = 0; j < n_mine; ++j) {
-        const int a = sl + j * nsl;
-        const unsigned m = __builtin_amdgcn_readfirstlane(s_mask[a]);
-        float g[TI];
+    const int j_last = n_mine - 1;
+    if (n_mine > 0) {
 #pragma unroll
-        for (int r = 0; r < TI; ++r) g[r] = s_g[a][r];  // two ds_read_b128, same address in every lane
-        float x0[KPT], x1[KPT];
+        for (int s = 0; s < kRing; ++s) load_x(min(s, j_last), xr0[s], xr1[s]);
+    }
+    for (int jb = 0; jb < n_mine; jb += kRing) {
 #pragma unroll
-        for (int v = 0; v < KPT; ++v) { x0[v] = xn0[v]; x1[v] = xn1[v]; }
-        if (j + 1 < n_mine) load_x(j + 1);
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            {
+                const int a = sl + min(j, j_last) * nsl;
+                const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[a]) : 0u;
+                float g[TI];
 #pragma unroll
-        for (int r = 0; r < TI; ++r) {
-            if (m & (1u << r)) {
+                for (int r = 0; r < TI; ++r) g[r] = s_g[a][r];  // two ds_read_b128, same address in every lane
+                float x0[KPT], x1[KPT];
 #pragma unroll
-                for (int v = 0; v < KPT; ++v) {
-                    if constexpr (CP) {
-                        Cplx dq, dx;
-                        pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
-                        dq0[r][v] += dq.re;
-                        dq1[r][v] += dq.im;
-                    } else {
-                        float dq, dx, e0 = 0.f;
-                        pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
-                        dq0[r][v] += dq;
-                        extra += g[r] * e0;
+                for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
+#ifndef MKB_ABL_NOLOAD
+                load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
+#endif
+#pragma unroll
+                for (int r = 0; r < TI; ++r) {
+                    if (m & (1u << r)) {
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) {
+                                Cplx dq, dx;
+                                pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
+                                dq0[r][v] += dq.re;
+                                dq1[r][v] += dq.im;
+                            } else {
+                                float dq, dx, e0 = 0.f;
+                                pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
+                                dq0[r][v] += dq;
+                                extra += g[r] * e0;
+                            }
+                        }
                     }
                 }
             }
@@ -334,10 +377,12 @@ __global__ __launch_bounds__(kWG) void pool_bwd_x_kernel(PoolArgs A) {
     __shared__ int s_wave_cnt[kWaves16];
 
     const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * TI;
+    // 1-D grid, tile-major: the workgroups of the low position tiles (used by every row: the heavy ones) are
+    // dispatched first, one per CU; the light / empty tiles fill in behind them.
+    const int nsl = A.x_slices, sl = blockIdx.x % nsl;
+    const int p0 = (blockIdx.x / nsl) * TI;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
-    const int nsl = gridDim.y, sl = blockIdx.y;
     const int rows_per = (A.B + nsl - 1) / nsl;  // <= 1024 (host picks nsl)
     const int i_own = sl * rows_per + tid;
 
@@ -381,40 +426,56 @@ __global__ __launch_bounds__(kWG) void pool_bwd_x_kernel(PoolArgs A) {
     }
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
 
-    float qn0[KPT], qn1[KPT];
-    auto load_q = [&](int j) {
+    float qr0[kRing][KPT], qr1[kRing][KPT];
+    auto load_q = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
         const float *q = A.Q + (int64_t)__builtin_amdgcn_readfirstlane(s_i[j]) * A.De;
 #pragma unroll
         for (int v = 0; v < KPT; ++v) {
             const bool ok = u0 + v < NU;
-            qn0[v] = ok ? q[u0 + v] : 0.f;
-            qn1[v] = (CP && ok) ? q[A.d + u0 + v] : 0.f;
+            const int uu = min(u0 + v, NU - 1);
+            const float l0 = q[uu];
+            const float l1 = CP ? q[A.d + uu] : 0.f;
+            d0[v] = ok ? l0 : 0.f;
+            d1[v] = ok ? l1 : 0.f;
         }
     };
-    if (n_rows > 0) load_q(0);
-    for (int j = 0; j < n_rows; ++j) {
-        const unsigned m = __builtin_amdgcn_readfirstlane(s_mask[j]);
-        float g[TI];
+    const int j_last = n_rows - 1;
+    if (n_rows > 0) {
 #pragma unroll
-        for (int t = 0; t < TI; ++t) g[t] = s_g[j][t];
-        float q0[KPT], q1[KPT];
+        for (int s = 0; s < kRing; ++s) load_q(min(s, j_last), qr0[s], qr1[s]);
+    }
+    for (int jb = 0; jb < n_rows; jb += kRing) {
 #pragma unroll
-        for (int v = 0; v < KPT; ++v) { q0[v] = qn0[v]; q1[v] = qn1[v]; }
-        if (j + 1 < n_rows) load_q(j + 1);
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            {
+                const int jc = min(j, j_last);
+                const unsigned m = (j < n_rows) ? __builtin_amdgcn_readfirstlane(s_mask[jc]) : 0u;
+                float g[TI];
 #pragma unroll
-        for (int t = 0; t < TI; ++t) {
-            if (m & (1u << t)) {
+                for (int t = 0; t < TI; ++t) g[t] = s_g[jc][t];
+                float q0[KPT], q1[KPT];
 #pragma unroll
-                for (int v = 0; v < KPT; ++v) {
-                    if constexpr (CP) {
-                        Cplx dq, dx;
-                        pair_bwd_cmod(Cplx{q0[v], q1[v]}, Cplx{x0[t][v], x1[t][v]}, g[t], dq, dx);
-                        dx0[t][v] += dx.re;
-                        dx1[t][v] += dx.im;
-                    } else {
-                        float dq, dx, e0 = 0.f;
-                        pair_bwd_real<MODEL, HEAD>(q0[v], x0[t][v], g[t], A.kd, modulus, dq, dx, e0);
-                        dx0[t][v] += dx;
+                for (int v = 0; v < KPT; ++v) { q0[v] = qr0[s][v]; q1[v] = qr1[s][v]; }
+#ifndef MKB_ABL_NOLOAD
+                load_q(min(j + kRing, j_last), qr0[s], qr1[s]);
+#endif
+#pragma unroll
+                for (int t = 0; t < TI; ++t) {
+                    if (m & (1u << t)) {
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) {
+                                Cplx dq, dx;
+                                pair_bwd_cmod(Cplx{q0[v], q1[v]}, Cplx{x0[t][v], x1[t][v]}, g[t], dq, dx);
+                                dx0[t][v] += dx.re;
+                                dx1[t][v] += dx.im;
+                            } else {
+                                float dq, dx, e0 = 0.f;
+                                pair_bwd_real<MODEL, HEAD>(q0[v], x0[t][v], g[t], A.kd, modulus, dq, dx, e0);
+                                dx0[t][v] += dx;
+                            }
+                        }
                     }
                 }
             }
@@ -591,7 +652,8 @@ static int run_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t 
     A.g_modulus = gr->g_modulus;
     const int NU = units_of(tb);
     dim3 gq((unsigned)((B + TI - 1) / TI), kBwdQSlices);
-    dim3 gx((unsigned)((P + TI - 1) / TI), (unsigned)w.x_slices);
+    dim3 gx((unsigned)(((P + TI - 1) / TI) * w.x_slices));
+    A.x_slices = w.x_slices;
     {
         ProfScope ps(MKB_PROF_POOL_BWD, st);
         if (NU <= kWG) {
