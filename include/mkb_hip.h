@@ -146,9 +146,12 @@ int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the
  * candidate list and filter bias of datasets.base.TestDataset (datasets/base.py:196-241): for each test triple
  * the rank of the target among all n_entity candidates, other true triples biased by -100000.
- *   true_keys: sorted int64 keys ((h*n_relation + r)*n_entity + t) of all true triples (device);
- *   rank [B] int64 out (1-based).
+ *   true_keys: ascending int64 keys of ALL true triples (device), ordered for the mode so that one query's
+ *   filter set is a contiguous range: tail-batch (h*n_relation + r)*n_entity + t, head-batch
+ *   (t*n_relation + r)*n_entity + h.  rank [B] int64 out (1-based; ties count in the target's favour).
+ *   ws: mkb_rank_workspace_bytes(tb, B) bytes, 256-byte aligned (queries + the [B, n_entity] score block).
  */
+int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B);
 int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
              int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream);
 

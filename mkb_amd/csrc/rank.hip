@@ -1,0 +1,234 @@
+// mkb_rank: filtered link-prediction rank of each test triple's target among ALL entities, on the device.
+//
+// Replaces evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) together
+// with the candidate list / filter bias that datasets.base.TestDataset builds per item on the host
+// (datasets/base.py:196-241): candidates are the n_entity ids in order; a candidate whose corrupted triple is
+// ANOTHER true triple gets bias -100000 (i.e. can never outrank the target); rank = 1 + number of candidates
+// scoring above the target (the reference reads it off a descending argsort, evaluation.py:245-262).
+//
+// Kernel 1  all_fwd : scores of B queries against every entity row.  Same lane-owns-dims tiling as the pooled
+//           forward (8 rows per 1024-lane workgroup, swap/DPP wave reduction, LDS cross-wave combine per 16
+//           candidates) but the candidates are simply consecutive table rows, split into slices over grid.y.
+// Kernel 2  rank    : one wave per query: count scores above the target's, then walk the query's true set
+//           (a contiguous range of the sorted key array) and take back the ones that were counted.
+#include "common.h"
+#include "model_math.h"
+
+namespace mkb {
+
+constexpr int kWGr = 1024, kWavesR = 16, TIr = 8, kSlabR = 16;
+
+struct AllArgs {
+    const float *ent, *Q;
+    float *S;  // [B, N]
+    const float *modulus;
+    int B, d;
+    int64_t N, De;
+    float kd, c0, c1;
+};
+
+__device__ __forceinline__ void reduce8_wave_r(const float (&v)[8], float &t0, float &t1) {
+    float w[4], u[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+        w[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 2]), false, false);
+        u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float t = u[j];
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x128, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x141, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0xB1, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x4E, 0xf, 0xf, false));
+        u[j] = t;
+    }
+    t0 = u[0];
+    t1 = u[1];
+}
+
+template <int MODEL, bool HEAD, int KPT>
+__global__ __launch_bounds__(kWGr) void all_fwd_kernel(AllArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    __shared__ float s_part[2][kSlabR][kWavesR][TIr];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * TIr;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = tid * KPT;
+    float q0[TIr][KPT], q1[TIr][KPT];
+#pragma unroll
+    for (int r = 0; r < TIr; ++r)
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            const bool ok = (i0 + r < A.B) && (u0 + v < NU);
+            const float *qrow = A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De;
+            const int uu = min(u0 + v, NU - 1);
+            const float l0 = qrow[uu], l1 = CP ? qrow[A.d + uu] : 0.f;
+            q0[r][v] = ok ? l0 : 0.f;
+            q1[r][v] = ok ? l1 : 0.f;
+        }
+    const int64_t per = (A.N + gridDim.y - 1) / gridDim.y;
+    const int64_t e_lo = (int64_t)blockIdx.y * per;
+    const int64_t e_hi = min(A.N, e_lo + per);
+    const int n_mine = (int)max((int64_t)0, e_hi - e_lo);
+    for (int j = 0; j < n_mine; ++j) {
+        const float *x = A.ent + (e_lo + j) * A.De;
+        float x0[KPT], x1[KPT];
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            const bool ok = u0 + v < NU;
+            const int uu = min(u0 + v, NU - 1);
+            const float l0 = x[uu], l1 = CP ? x[A.d + uu] : 0.f;
+            x0[v] = ok ? l0 : 0.f;
+            x1[v] = ok ? l1 : 0.f;
+        }
+        float part[TIr];
+#pragma unroll
+        for (int r = 0; r < TIr; ++r) {
+            part[r] = 0.f;
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) {
+                if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
+                else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+            }
+        }
+        float t0, t1;
+        reduce8_wave_r(part, t0, t1);
+        const int jj = j % kSlabR, buf = (j / kSlabR) & 1;
+        if ((lane & 15) == 0) {
+            const int R = lane >> 4, r = 4 * (R >> 1) + 2 * (R & 1);
+            s_part[buf][jj][wave][r] = t0;
+            s_part[buf][jj][wave][r + 1] = t1;
+        }
+        if (jj == kSlabR - 1 || j == n_mine - 1) {
+            __syncthreads();
+            const int j0 = j - jj, nb = jj + 1;
+            if (tid < nb * TIr) {
+                const int cj = tid % nb, r = tid / nb;  // consecutive lanes -> consecutive candidates (coalesced store)
+                if (i0 + r < A.B) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kWavesR; ++w) sum += s_part[buf][cj][w][r];
+                    if constexpr (MODEL == MKB_PROTATE) sum *= A.modulus[0];
+                    A.S[(int64_t)(i0 + r) * A.N + e_lo + j0 + cj] = A.c0 + A.c1 * sum;
+                }
+            }
+        }
+    }
+}
+
+// one wave per query
+__global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, const int64_t *__restrict__ sample, int B,
+                                                   int64_t N, int64_t R, int head_mode,
+                                                   const int64_t *__restrict__ keys, int64_t nk,
+                                                   int64_t *__restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
+    const int64_t target = head_mode ? h : t;
+    const float *row = S + (int64_t)i * N;
+    const float st = row[target];
+    int64_t cnt = 0;
+    for (int64_t e = lane; e < N; e += 64) cnt += row[e] > st ? 1 : 0;
+    // other true triples (base.py:213-216 / 229-232): take back those that were counted
+    const int64_t base = ((head_mode ? t : h) * R + r) * N;  // keys of this (fixed entity, relation) pair are contiguous
+    int64_t lo = 0, hi = nk;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (keys[mid] < base) lo = mid + 1; else hi = mid; }
+    for (int64_t k = lo + lane; k < nk; k += 64) {
+        const int64_t key = keys[k];
+        if (key >= base + N) break;
+        const int64_t e = key - base;
+        if (e != target && row[e] > st) cnt -= 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) rank[i] = cnt + 1;
+}
+
+struct RowArgsR {
+    const float *ent, *rel;
+    const int64_t *sample;
+    float *Q;
+    int64_t De, Dr;
+    int d;
+    float kd;
+};
+
+template <int MODEL, bool HEAD>
+__global__ __launch_bounds__(256) void query_build_kernel_r(RowArgsR A) {
+    const int64_t i = blockIdx.x;
+    const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
+    const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
+    float *q = A.Q + i * A.De;
+    if constexpr (ModelTraits<MODEL>::cplx_query) {
+        const float *e = HEAD ? et : eh;
+        for (int u = threadIdx.x; u < A.d; u += 256) {
+            Cplx qq = build_q_cplx<MODEL, HEAD>(Cplx{e[u], e[A.d + u]}, Cplx{er[u], MODEL == MKB_COMPLEX ? er[A.d + u] : 0.f}, A.kd);
+            q[u] = qq.re;
+            q[A.d + u] = qq.im;
+        }
+    } else {
+        for (int u = threadIdx.x; u < (int)A.De; u += 256)
+            q[u] = build_q_real<MODEL, HEAD>(HEAD ? er[u] : eh[u], HEAD ? et[u] : er[u], A.kd);
+    }
+}
+
+template <int MODEL, bool HEAD>
+static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, const int64_t *keys, int64_t nk, int64_t *rank,
+                    float *Q, float *S, hipStream_t st) {
+    RowArgsR ra{tb->ent, tb->rel, sample, Q, tb->entity_dim, tb->relation_dim, tb->hidden_dim, tb->phase_div};
+    hipLaunchKernelGGL((query_build_kernel_r<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
+    AllArgs A{tb->ent, Q, S, tb->modulus, (int)B, tb->hidden_dim, tb->n_entity, tb->entity_dim, tb->phase_div,
+              ModelTraits<MODEL>::uses_gamma ? tb->gamma : 0.f, ModelTraits<MODEL>::uses_gamma ? -1.f : 1.f};
+    const int tiles = (int)((B + TIr - 1) / TIr);
+    int slices = (512 + tiles - 1) / tiles;  // aim for >= 2 workgroups per CU
+    if (slices < 1) slices = 1;
+    if ((int64_t)slices > tb->n_entity) slices = (int)tb->n_entity;
+    dim3 grid((unsigned)tiles, (unsigned)slices);
+    const int NU = tb->model == MKB_ROTATE ? tb->hidden_dim : (int)tb->entity_dim;
+    if (NU <= kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 1>), grid, dim3(kWGr), 0, st, A);
+    else if (NU <= 2 * kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 2>), grid, dim3(kWGr), 0, st, A);
+    else hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 4>), grid, dim3(kWGr), 0, st, A);
+    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
+                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+}  // namespace mkb
+
+using namespace mkb;
+
+extern "C" int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B) {
+    if (!tb || B <= 0) return 0;
+    return (int64_t)(((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255) + (int64_t)B * tb->n_entity * 4;
+}
+
+extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+                        int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream) {
+    if (int rc = validate_tables(tb)) return rc;
+    MKB_REQUIRE(sample && rank && ws && (true_keys || n_true == 0), "null pointer");
+    MKB_REQUIRE(mode == MKB_MODE_HEAD || mode == MKB_MODE_TAIL, "mkb_rank needs head-batch or tail-batch");
+    MKB_REQUIRE(B > 0 && B <= INT32_MAX, "bad B");
+    MKB_REQUIRE(ws_bytes >= mkb_rank_workspace_bytes(tb, B) && (((uintptr_t)ws) & 255) == 0, "workspace too small / unaligned");
+    const int NU = tb->model == MKB_ROTATE ? tb->hidden_dim : (int)tb->entity_dim;
+    MKB_REQUIRE(NU <= 4 * kWGr, "rows of more than 4096 units are not supported");
+    float *Q = (float *)ws;
+    float *S = (float *)((unsigned char *)ws + (((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255));
+    hipStream_t st = (hipStream_t)stream;
+    const bool head = mode == MKB_MODE_HEAD;
+    switch (tb->model) {
+        case MKB_TRANSE: return head ? run_rank<MKB_TRANSE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_TRANSE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+        case MKB_ROTATE: return head ? run_rank<MKB_ROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_ROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+        case MKB_COMPLEX: return head ? run_rank<MKB_COMPLEX, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_COMPLEX, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+        case MKB_DISTMULT: return head ? run_rank<MKB_DISTMULT, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_DISTMULT, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+        case MKB_PROTATE: return head ? run_rank<MKB_PROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_PROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+    }
+    return set_error(MKB_ERR_INVALID, "unknown model");
+}

@@ -1,17 +1,23 @@
 """``Evaluation`` -- filtered link-prediction metrics MRR / MR / HITS@1/3/10 (reference
 mkb/evaluation/evaluation.py:137-279) with the same constructor and return dictionaries.
 
-Scores come from the same HIP forward as training (``model(sample, negative_sample, mode)`` with all
-``n_entity`` candidates); the filter bias and candidate lists are those of ``datasets.base.TestDataset``.
-The rank of the target is read off a descending argsort on the device, as the reference does on the host
-(evaluation.py:245-262), so ties are broken by the sort, not by a convention of ours.
+``eval`` on a ROCm device runs ``mkb_rank``: every test triple is scored against ALL entity rows by a tiled HIP
+kernel (no ``[B, N, D]`` gather, no per-item python loop over ``n_entity`` candidates as in
+``datasets.base.TestDataset``, base.py:196-241) and the filtered rank is counted on the device; exact score ties
+count in the target's favour.  ``force_reference_path = True`` (and ``eval_relations`` always) takes the
+reference's route instead: ``TestDataset`` candidate lists + filter bias, ``model(sample, negative_sample, mode)``
+through the general HIP forward, rank read off a descending argsort (evaluation.py:245-262).
 """
 import collections
+import ctypes
 
+import numpy as np
 import torch
 from torch.utils import data
 
+from .. import _hip
 from ..datasets import base
+from ..models.base import BaseModel
 from ..utils import Bar, Mean
 
 __all__ = ["Evaluation"]
@@ -41,8 +47,59 @@ class Evaluation:
         return data.DataLoader(dataset=test_dataset, batch_size=self.batch_size, num_workers=self.num_workers,
                                collate_fn=base.TestDatasetRelation.collate_fn)
 
+    # ------------------------------------------------------------------ device ranking (mkb_rank)
+    def _true_keys(self, device, n_entity, n_relation):
+        """Sorted keys of all true triples, one ordering per mode (cached on the device)."""
+        cache = getattr(self, "_keys_cache", None)
+        if cache is None or cache[0] != (device, len(self.true_triples)):
+            a = np.asarray(self.true_triples, dtype=np.int64).reshape(-1, 3)
+            h, r, t = a[:, 0], a[:, 1], a[:, 2]
+            tail = np.unique((h * n_relation + r) * n_entity + t)
+            head = np.unique((t * n_relation + r) * n_entity + h)
+            cache = ((device, len(self.true_triples)),
+                     {"head-batch": torch.as_tensor(head, device=device), "tail-batch": torch.as_tensor(tail, device=device)})
+            self._keys_cache = cache
+        return cache[1]
+
+    def ranks(self, model, dataset, mode, chunk=1024):
+        """Filtered rank (1-based) of every triple of ``dataset`` in ``mode``, computed on the device: int64 tensor."""
+        dev = model.entity_embedding.device
+        _hip.require_device(model.entity_embedding)
+        keys = self._true_keys(dev, model.n_entity, model.n_relation)[mode]
+        triples = torch.as_tensor(np.asarray(dataset, dtype=np.int64).reshape(-1, 3), device=dev)
+        out = torch.empty(len(triples), dtype=torch.int64, device=dev)
+        lib, tb = _hip.lib(), model._tables()
+        ws = None
+        with torch.cuda.device(dev):
+            for lo in range(0, len(triples), chunk):
+                s = triples[lo: lo + chunk].contiguous()
+                need = lib.mkb_rank_workspace_bytes(tb, s.shape[0])
+                if ws is None or ws.numel() < need + 256:
+                    ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+                off = (-ws.data_ptr()) % 256
+                _hip.check(lib.mkb_rank(tb, _hip.ptr(s), s.shape[0], _hip.mode_id(mode), _hip.ptr(keys), keys.numel(),
+                                        _hip.ptr(out[lo: lo + chunk]), ctypes.c_void_p(ws.data_ptr() + off), need,
+                                        _hip.stream_ptr()),
+                           "mkb_rank")
+        return out
+
+    def _device_ok(self, model):
+        units = model.hidden_dim if model.name == "RotatE" else model.entity_dim
+        return (isinstance(model, BaseModel) and model.entity_embedding.is_cuda and str(self.device) != "cpu"
+                and units <= 4096 and len(self.true_triples) > 0)
+
     def eval(self, model, dataset):
         metrics = collections.OrderedDict({m: Mean() for m in ["MRR", "MR", "HITS@1", "HITS@3", "HITS@10"]})
+        if self._device_ok(model) and not getattr(self, "force_reference_path", False):
+            with torch.no_grad():
+                for mode in ("head-batch", "tail-batch"):  # same order as get_entity_stream
+                    for ranking in self.ranks(model, dataset, mode).tolist():
+                        metrics["MRR"].update(1.0 / ranking)
+                        metrics["MR"].update(ranking)
+                        metrics["HITS@1"].update(1.0 if ranking <= 1 else 0.0)
+                        metrics["HITS@3"].update(1.0 if ranking <= 3 else 0.0)
+                        metrics["HITS@10"].update(1.0 if ranking <= 10 else 0.0)
+            return {name: round(metric.get(), 4) for name, metric in metrics.items()}
         with torch.no_grad():
             for test_set in self.get_entity_stream(dataset):
                 metrics = self.compute_score(model=model, test_set=test_set, metrics=metrics, device=self.device)

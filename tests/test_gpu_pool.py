@@ -217,3 +217,20 @@ def test_sharded_batch_with_global_weight_sum_equals_full_batch():
     np.testing.assert_allclose(total, full_loss, rtol=0, atol=1e-6)
     np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), g_full[0].cpu().numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), g_full[1].cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"])
+def test_device_ranking_equals_reference_route(name):
+    """mkb_rank (tiled all-entity forward + on-device filtered count) == TestDataset + general forward + argsort."""
+    from mkb_amd import datasets, evaluation, models
+
+    ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(3)
+    m = getattr(models, name)(hidden_dim=37, entities=ds.entities, relations=ds.relations, gamma=6).cuda().eval()
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=64,
+                               device="cuda", num_workers=0)
+    test = ds.test[:150]
+    fast = ev.eval(model=m, dataset=test)
+    ev.force_reference_path = True
+    slow = ev.eval(model=m, dataset=test)
+    assert fast == slow, (fast, slow)
