@@ -142,6 +142,21 @@ int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int6
 int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, float lr,
                   float beta1, float beta2, float eps, int zero_grad, void *stream);
 
+/* Row-lazy form of the same dense Adam (identical arithmetic, see mkb_amd/csrc/adam.hip): `last` [n_rows] int32
+ * (zero-initialised) holds the step each row is current through, `consts` [capacity, 2] float holds the per-step
+ * scalars recorded by mkb_adam_rows_step.
+ *   mkb_adam_rows_catchup: replay the pending zero-gradient steps of the rows in ids (null = every row, i.e. a
+ *     flush) so that they are current through step_upto;
+ *   mkb_adam_rows_step: apply step `step` with the real gradient to the rows in ids (duplicates allowed; they must
+ *     be current through step-1) and clear their gradient rows.
+ */
+int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts, int64_t n_rows,
+                          int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float beta1, float beta2,
+                          float eps, void *stream);
+int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                       int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr, float beta1,
+                       float beta2, float eps, void *stream);
+
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the
  * candidate list and filter bias of datasets.base.TestDataset (datasets/base.py:196-241): for each test triple

@@ -15,15 +15,18 @@ namespace mkb {
 // Same operation order as torch 2.x _single_tensor_adam on CPU so results track the reference to ~1 ulp:
 //   exp_avg.lerp_(grad, 1-b1)  -> fma(1-b1, g-m, m)        (ATen lerp, weight < 0.5)
 //   exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1-b2) -> v*b2 + ((1-b2)*g)*g
-//   denom = sqrt(v) / sqrt(bc2) + eps ;  p += (-step_size * m) / denom
+//   denom = sqrt(v) / sqrt(bc2) + eps ;  p += (-step_size * m) / denom     (sqrt and the two divisions at 1 ulp)
 __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float w1, float b2, float w2,
                                          float neg_step, float sqrt_bc2, float eps) {
 #pragma clang fp contract(off)
     m = fmaf(w1, g - m, m);
     v = v * b2;
     v = v + (w2 * g) * g;
-    const float denom = sqrtf(v) / sqrt_bc2 + eps;
-    p = p + (neg_step * m) / denom;
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and '/' (~30 instructions per
+    // element): the update is lr-sized, so the deviation from torch's result is ~1e-7 of 5e-5 per step.  The dense
+    // and the row-lazy kernels share this code, which is what keeps them bit-identical to each other.
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(sqrt_bc2) + eps;
+    p = p + (neg_step * m) * __builtin_amdgcn_rcpf(denom);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
@@ -71,6 +74,133 @@ extern "C" int mkb_adam_step(float *param, float *grad, float *exp_avg, float *e
     mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
     hipLaunchKernelGGL(mkb::adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, w1, beta2, w2, neg_step, sqrt_bc2, eps, zero_grad);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+// =====================================================================================================
+// Row-lazy dense Adam: identical arithmetic, HBM traffic proportional to the rows a step touches.
+//
+// Dense Adam moves EVERY row every step (rows with a zero gradient still decay their moments and drift along the
+// stale momentum), which makes the optimizer the largest HBM consumer of a KGE step: 8 x 116 MB per step at the
+// headline config for ~2,400 touched rows out of 14,541.  But a row's zero-gradient steps depend on nothing but the
+// row itself and the per-step scalars (lr / bias corrections), so they can be DEFERRED: `last[row]` records the
+// step a row is current through; before a step reads a row (it is in the batch's pool / heads / tails) the
+// pending zero-gradient steps are replayed in registers (same operations, same order, same rounding as the dense
+// kernel would have applied them), and after backward only the touched rows take the real step.  A flush replays
+// everything that is pending (before evaluation, checkpointing, or any direct read of the table).
+// Rows that were never touched have m = v = 0, for which a dense step is the identity: they are skipped.
+// consts[s] = (-lr / (1 - beta1^s), sqrt(1 - beta2^s)) is recorded by the step kernel for later replays.
+
+namespace mkb {
+
+struct AdamRowArgs {
+    float *p, *g, *m, *v;
+    int32_t *last;
+    float2 *consts;
+    const int64_t *ids;  // rows to process (duplicates allowed), or null = all rows (flush)
+    int64_t D;
+    int32_t step;        // catch-up / flush: bring rows to `step`; step kernel: apply `step`
+    float w1, b2, w2, eps, neg_step, sqrt_bc2;
+};
+
+__device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
+                                                    float sqrt_bc2, float eps) {
+#pragma clang fp contract(off)
+    m = fmaf(w1, 0.f - m, m);  // the dense kernel's fmaf(w1, g - m, m) at g = 0
+    v = v * b2;                // ... + (w2 * 0) * 0 adds +0
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the correctly rounded sqrtf and '/' (~30 instructions per
+    // element): the update is lr-sized, so the deviation from torch's result is ~1e-7 of 5e-5 per step.  The dense
+    // and the row-lazy kernels share this code, which is what keeps them bit-identical to each other.
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(sqrt_bc2) + eps;
+    p = p + (neg_step * m) * __builtin_amdgcn_rcpf(denom);
+}
+
+// replay the zero-gradient steps (from, to] of one row; 256 lanes, float4 per lane, whole row in registers
+__device__ __forceinline__ void replay_row(const AdamRowArgs &A, int64_t row, int from, int to) {
+    float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
+    for (int64_t k = (int64_t)threadIdx.x * 4; k < A.D; k += 1024) {
+        const bool vec = k + 4 <= A.D;
+        float pp[4], mm[4], vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = vec || k + e < A.D;
+            pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+        }
+        for (int s = from + 1; s <= to; ++s) {
+            const float2 c = A.consts[s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (vec || k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_rows_catchup_kernel(AdamRowArgs A) {
+    __shared__ int s_old;
+    const int64_t row = A.ids ? A.ids[blockIdx.x] : (int64_t)blockIdx.x;
+    if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
+    __syncthreads();
+    const int old = s_old;
+    if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
+    replay_row(A, row, old, A.step);
+}
+
+__global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
+    __shared__ int s_old;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
+    const int64_t row = A.ids[blockIdx.x];
+    if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
+    __syncthreads();
+    if (s_old == A.step) return;  // duplicate id: another workgroup owns this row
+    float *p = A.p + row * A.D, *g = A.g + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
+    for (int64_t k = threadIdx.x; k < A.D; k += 256) {
+        float pp = p[k], mm = m[k], vv = v[k];
+        adam_one(pp, g[k], mm, vv, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
+        p[k] = pp; m[k] = mm; v[k] = vv; g[k] = 0.f;
+    }
+}
+
+static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float *v, int32_t *last, float *consts,
+                     const int64_t *ids, int64_t D, int64_t step, float lr, float beta1, float beta2, float eps) {
+    MKB_REQUIRE(param && m && v && last && consts, "null pointer");
+    MKB_REQUIRE(D > 0 && step >= 0 && step < INT32_MAX, "bad D / step");
+    A.p = param; A.g = grad; A.m = m; A.v = v; A.last = last; A.consts = (float2 *)consts; A.ids = ids; A.D = D;
+    A.step = (int32_t)step;
+    A.w1 = (float)(1.0 - (double)beta1); A.b2 = beta2; A.w2 = (float)(1.0 - (double)beta2); A.eps = eps;
+    const double s = step > 0 ? (double)step : 1.0;
+    A.neg_step = (float)(-((double)lr / (1.0 - pow((double)beta1, s))));
+    A.sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, s));
+    return MKB_OK;
+}
+
+}  // namespace mkb
+
+extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                     int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto,
+                                     float beta1, float beta2, float eps, void *stream) {
+    mkb::AdamRowArgs A;
+    if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, 0.f, beta1, beta2, eps)) return rc;
+    const int64_t n = ids ? n_ids : n_rows;
+    if (n <= 0 || step_upto <= 0) return MKB_OK;
+    MKB_REQUIRE(n <= INT32_MAX, "too many rows");
+    mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
+    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+extern "C" int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                  int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr,
+                                  float beta1, float beta2, float eps, void *stream) {
+    (void)n_rows;
+    mkb::AdamRowArgs A;
+    if (int rc = mkb::fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, ids, D, step, lr, beta1, beta2, eps)) return rc;
+    MKB_REQUIRE(grad && ids && step >= 1 && n_ids > 0 && n_ids <= INT32_MAX, "bad arguments");
+    mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
+    hipLaunchKernelGGL(mkb::adam_rows_step_kernel, dim3((unsigned)n_ids), dim3(256), 0, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

@@ -65,6 +65,7 @@ class Evaluation:
         """Filtered rank (1-based) of every triple of ``dataset`` in ``mode``, computed on the device: int64 tensor."""
         dev = model.entity_embedding.device
         _hip.require_device(model.entity_embedding)
+        model.sync_parameters()
         keys = self._true_keys(dev, model.n_entity, model.n_relation)[mode]
         triples = torch.as_tensor(np.asarray(dataset, dtype=np.int64).reshape(-1, 3), device=dev)
         out = torch.empty(len(triples), dtype=torch.int64, device=dev)

@@ -115,6 +115,12 @@ class FusedTrainStep:
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ws = _workspace(m, B, K)
         gr = self._grad_buffers()
+        ent = m.entity_embedding
+        lazy = getattr(ent, "_mkb_lazy", None)
+        if lazy is not None:  # row-lazy Adam: the rows this step reads must be current before the forward pass
+            ids = torch.cat([info.pool, sample[:, 0], sample[:, 2]])
+            lazy.catch_up(ent, ids)
+            ent._mkb_touched = ids
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
                                                 _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(weight_sum),

@@ -78,6 +78,8 @@ class Base(nn.Module):
             k.rjust(l_len) + "  " + v.ljust(r_len) for k, v in self._repr_content.items())
 
     def save(self, path):
+        if hasattr(self, "sync_parameters"):
+            self.sync_parameters()
         with open(path, "wb") as handle:
             pickle.dump(self.cpu().eval(), handle, protocol=pickle.HIGHEST_PROTOCOL)
 
@@ -133,9 +135,18 @@ class BaseModel(Base):
                            self.relation_dim, ent.data_ptr(), rel.data_ptr(),
                            None if modulus is None else modulus.data_ptr(), gamma, phase_div)
 
+    def sync_parameters(self):
+        """Bring the tables up to date when a row-lazy optimizer (mkb_amd.optim.Adam(lazy_rows=True)) is attached;
+        no-op otherwise.  Called before any read of the tables outside the fused training step."""
+        for p in (self.entity_embedding, self.relation_embedding):
+            opt = getattr(p, "_mkb_lazy", None)
+            if opt is not None:
+                opt.flush(p)
+
     # ------------------------------------------------------------------ reference API
     @property
     def embeddings(self):
+        self.sync_parameters()
         ent = self.entity_embedding.detach()
         rel = self.relation_embedding.detach()
         return {"entities": {self.entities[i]: ent[i] for i in range(self.n_entity)},
@@ -164,6 +175,7 @@ class BaseModel(Base):
 
     def forward(self, sample, negative_sample=None, mode=None):
         _hip.require_device(self.entity_embedding, sample, negative_sample)
+        self.sync_parameters()
         sample, shape = self.format_sample(sample=sample, negative_sample=negative_sample)
         mode_id = _hip.mode_id(mode)
         sample = _hip.contiguous(sample, torch.int64)

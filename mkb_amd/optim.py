@@ -6,6 +6,14 @@ Opt-in: ``torch.optim.Adam`` keeps working with ``mkb_amd`` models (gradients ar
 tensors).  Dense means dense: every row of the tables moves every step through its moments, exactly like the
 reference -- rows with a zero gradient still decay ``exp_avg`` / ``exp_avg_sq`` and step along the stale
 momentum.
+
+``Adam(..., lazy_rows=True)`` keeps those semantics bit for bit but defers the zero-gradient steps of the rows a
+step does not touch (``mkb_adam_rows_catchup`` / ``mkb_adam_rows_step``, see mkb_amd/csrc/adam.hip): the fused
+training step tells the optimizer which entity rows it reads (candidate pool + heads + tails); those rows are
+brought up to date before the forward pass and take the real step afterwards; everything else is replayed when
+it is next needed or at ``flush()`` (``compose.Pipeline`` / ``evaluation`` / ``model(...)`` outside the fused
+step / ``model.embeddings`` / ``model.save`` flush automatically; flush by hand before reading
+``model.entity_embedding`` directly).
 """
 import torch
 
@@ -15,13 +23,68 @@ __all__ = ["Adam"]
 
 
 class Adam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False):
         self.params = [p for p in params]
         self.lr, self.betas, self.eps = lr, betas, eps
         self.state = {}
         self.step_count = 0
+        self.lazy_rows = lazy_rows
         self._zeroed = False
+        if lazy_rows:
+            for p in self.params:
+                if p.dim() == 2 and p.shape[0] >= 4096:  # big tables only; small ones stay on the dense kernel
+                    p._mkb_lazy = self
 
+    # ------------------------------------------------------------------ state
+    def _state(self, p):
+        st = self.state.get(p)
+        if st is None:
+            st = self.state[p] = {"m": torch.zeros_like(p), "v": torch.zeros_like(p), "n": 0}
+            if getattr(p, "_mkb_lazy", None) is self:
+                st["last"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
+                st["consts"] = torch.zeros((1 << 16, 2), dtype=torch.float32, device=p.device)
+        return st
+
+    def _consts(self, st, step):
+        c = st["consts"]
+        if step >= c.shape[0]:
+            new = torch.zeros((max(2 * c.shape[0], step + 1), 2), dtype=torch.float32, device=c.device)
+            new[: c.shape[0]] = c
+            st["consts"] = c = new
+        return c
+
+    # ------------------------------------------------------------------ lazy rows
+    def catch_up(self, p, ids, upto=None):
+        """Make the rows ``ids`` of ``p`` current through step ``upto`` (default: every step taken so far)."""
+        st = self._state(p)
+        upto = st["n"] if upto is None else upto
+        if upto <= 0:
+            return
+        ids = _hip.contiguous(ids, torch.int64)
+        with torch.cuda.device(p.device):
+            _hip.check(_hip.lib().mkb_adam_rows_catchup(_hip.ptr(p.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                        _hip.ptr(st["last"]), _hip.ptr(self._consts(st, upto)), p.shape[0],
+                                                        p.shape[1], _hip.ptr(ids), ids.numel(), upto, self.betas[0],
+                                                        self.betas[1], self.eps, _hip.stream_ptr()),
+                       "mkb_adam_rows_catchup")
+
+    def flush(self, p=None):
+        """Replay every pending zero-gradient step: afterwards the tables equal what dense Adam would hold."""
+        for q in ([p] if p is not None else self.params):
+            if getattr(q, "_mkb_lazy", None) is not self:
+                continue
+            st = self._state(q)
+            if st["n"] <= 0 or st.get("flushed") == st["n"]:
+                continue
+            with torch.cuda.device(q.device):
+                _hip.check(_hip.lib().mkb_adam_rows_catchup(_hip.ptr(q.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                            _hip.ptr(st["last"]), _hip.ptr(self._consts(st, st["n"])),
+                                                            q.shape[0], q.shape[1], None, 0, st["n"], self.betas[0],
+                                                            self.betas[1], self.eps, _hip.stream_ptr()),
+                           "mkb_adam_rows_catchup")
+            st["flushed"] = st["n"]
+
+    # ------------------------------------------------------------------ torch.optim-like API
     def step(self):
         self.step_count += 1
         lib = _hip.lib()
@@ -29,18 +92,31 @@ class Adam:
             if p.grad is None:
                 continue
             _hip.require_device(p)
-            st = self.state.get(p)
-            if st is None:
-                st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p), [0])
-            m, v, n = st
-            n[0] += 1
+            st = self._state(p)
             g = p.grad
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
+            touched = getattr(p, "_mkb_touched", None) if getattr(p, "_mkb_lazy", None) is self else None
             with torch.cuda.device(p.device):
-                _hip.check(lib.mkb_adam_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(m), _hip.ptr(v), p.numel(), n[0],
-                                             self.lr, self.betas[0], self.betas[1], self.eps, 1, _hip.stream_ptr()),
-                           "mkb_adam_step")
+                if touched is not None:
+                    st["n"] += 1
+                    ids = _hip.contiguous(touched, torch.int64)
+                    c = self._consts(st, st["n"])
+                    self.catch_up(p, ids, upto=st["n"] - 1)  # rows touched by OTHER data-parallel ranks only
+                    _hip.check(lib.mkb_adam_rows_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                      _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1],
+                                                      _hip.ptr(ids), ids.numel(), st["n"], self.lr, self.betas[0],
+                                                      self.betas[1], self.eps, _hip.stream_ptr()), "mkb_adam_rows_step")
+                    p._mkb_touched = None
+                else:
+                    if "last" in st:  # a step whose touched rows are unknown: fall back to dense for good
+                        self.flush(p)
+                        st.pop("last"), st.pop("consts")
+                        p._mkb_lazy = None
+                    st["n"] += 1
+                    _hip.check(lib.mkb_adam_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                 p.numel(), st["n"], self.lr, self.betas[0], self.betas[1], self.eps, 1,
+                                                 _hip.stream_ptr()), "mkb_adam_step")
         self._zeroed = True
 
     def zero_grad(self, set_to_none=False):

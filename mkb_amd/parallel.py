@@ -57,6 +57,7 @@ def allreduce_touched_rows(grad, local_ids, extras=(), group=None, dense_thresho
     dist.all_gather(gathered, padded, group=group)
     union = torch.unique(torch.cat(gathered))
     union = union[union >= 0]
+    allreduce_touched_rows.last_union = union
     extras = [e for e in extras if e is not None]
     flat_extra = [e.reshape(-1) for e in extras]
     if union.numel() >= dense_threshold * n:
@@ -108,6 +109,13 @@ class SparseGradExchange:
         extras.extend(extra_scalars)
         self.last_rows_moved = allreduce_touched_rows(m.entity_embedding.grad, ids, extras, self.group,
                                                       equal_counts=self.equal_batches)
+        if getattr(m.entity_embedding, "_mkb_lazy", None) is not None:
+            # row-lazy Adam must step every row ANY rank touched: hand it the gathered id list
+            m.entity_embedding._mkb_touched = self.last_union
+
+    @property
+    def last_union(self):
+        return allreduce_touched_rows.last_union
 
     def loss(self, local_loss):
         t = local_loss.detach().reshape(1).clone()
