@@ -189,7 +189,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kinds = ["pool_bwd", "pool_fwd", "adam", "sampler", "loss", "general_fwd", "general_bwd"]
+    kinds = ["pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam", "sampler", "loss", "general_fwd", "general_bwd"]
     # pick the dominant kernel class on a short probe unless told otherwise
     for i in range(args.warmup):
         run_step(ctx, i)
@@ -206,7 +206,7 @@ def main():
             n, ms = _hip.profile_read(k)
             tot[k] = ms
             _hip.profile_enable(k, False)
-        prof_kind = max(("pool_bwd", "pool_fwd", "adam"), key=lambda k: tot[k])
+        prof_kind = max(("pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam"), key=lambda k: tot[k])
         if args.breakdown and rank == 0:
             print("probe ms/step by kernel class:", {k: round(v / 8, 4) for k, v in tot.items()}, file=sys.stderr)
     if prof_kind != "none":
@@ -249,10 +249,10 @@ def main():
         else:
             # logical gather/scatter bytes of the reference formulation, per pass over the negatives:
             # every scored slot reads its entity row (fwd) / re-reads it and adds one gradient row (bwd)
-            passes = 1 if prof_kind == "pool_fwd" else 2
-            alg = passes * B * K * De * 4
-            what = (f"{prof_kind} kernel: logical bytes of the reference formulation ({passes} x B*K entity rows of "
-                    f"{De * 4} B); the kernel itself is VALU-bound and reuses each pool row from registers")
+            alg = B * K * De * 4
+            what = (f"{prof_kind} kernel: logical bytes of the reference formulation (B*K entity rows of {De * 4} B "
+                    f"gathered / re-read / scattered once by this pass); the kernel itself is VALU-bound and reuses "
+                    f"each pool row from registers, so the logical rate may exceed the HBM peak")
         ach = alg / avg_s / 1e9
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/traffic.json)
         try:

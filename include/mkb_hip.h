@@ -122,6 +122,7 @@ void mkb_sampler_destroy(mkb_sampler_t *s);
  *   (score of row i against pool position p, valid where cnt>0), loss [1] out; weight_sum as in
  *   mkb_adversarial (null = sum of this call's weights).
  */
+int mkb_pool_supported(const mkb_tables_t *tb, int64_t B, int64_t K); /* 1 if the pooled kernels cover this shape */
 int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K);
 int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                   const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
@@ -173,18 +174,19 @@ int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode,
 /* ---- per-kernel timing (measurement aid, no reference counterpart) -------------------------------------
  * When enabled, the launches of the named kernel class are bracketed by hipEvents recorded on the SAME stream
  * the kernel is launched on.  mkb_profile_read synchronises, returns the number of bracketed launches and
- * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward,
- * 1 = pooled forward, 2 = dense Adam, 3 = sampler (draw + filter), 4 = adversarial loss, 5 = general forward,
- * 6 = general backward.  At most 8192 launches are kept between reads.
+ * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward (dq pass),
+ * 1 = pooled forward, 2 = Adam, 3 = sampler (draw + filter), 4 = adversarial loss, 5 = general forward,
+ * 6 = general backward, 7 = pooled backward (dx pass).  At most 8192 launches are kept between reads.
  */
-#define MKB_PROF_POOL_BWD 0
+#define MKB_PROF_POOL_BWD_Q 0
 #define MKB_PROF_POOL_FWD 1
 #define MKB_PROF_ADAM 2
 #define MKB_PROF_SAMPLER 3
 #define MKB_PROF_LOSS 4
 #define MKB_PROF_GENERAL_FWD 5
 #define MKB_PROF_GENERAL_BWD 6
-#define MKB_PROF_KINDS 7
+#define MKB_PROF_POOL_BWD_X 7
+#define MKB_PROF_KINDS 8
 int mkb_profile_enable(int kernel, int on);
 int mkb_profile_read(int kernel, int64_t *launches, double *total_ms);
 

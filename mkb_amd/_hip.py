@@ -58,6 +58,7 @@ _SIGNATURES = {
     "mkb_sampler_get_state": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "mkb_sampler_set_state": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     "mkb_sampler_destroy": (None, [c_void_p]),
+    "mkb_pool_supported": (c_int, [POINTER(Tables), c_int64, c_int64]),
     "mkb_pool_step_workspace_bytes": (c_int64, [POINTER(Tables), c_int64, c_int64]),
     "mkb_pool_step": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                               c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -99,7 +100,8 @@ def lib():
     return _lib
 
 
-PROF_KINDS = {"pool_bwd": 0, "pool_fwd": 1, "adam": 2, "sampler": 3, "loss": 4, "general_fwd": 5, "general_bwd": 6}
+PROF_KINDS = {"pool_bwd_q": 0, "pool_fwd": 1, "adam": 2, "sampler": 3, "loss": 4, "general_fwd": 5, "general_bwd": 6,
+              "pool_bwd_x": 7}
 
 
 def profile_enable(kind, on=True):

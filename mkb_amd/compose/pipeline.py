@@ -12,7 +12,7 @@ README, or ``mkb_amd.optim.Adam``).
 """
 import collections
 
-from ..fused import FusedTrainStep
+from ..fused import FusedTrainStep, pooled_supported
 from ..losses import Adversarial
 from ..models.base import BaseModel
 from ..sampling import NegativeSampling
@@ -39,7 +39,8 @@ class Pipeline:
     def learn(self, model, dataset, sampling, optimizer, loss, evaluation=None):
         fused = None
         if (self.fuse and isinstance(model, BaseModel) and isinstance(sampling, NegativeSampling)
-                and type(loss) is Adversarial and 2 * sampling.size <= 1024):
+                and type(loss) is Adversarial and model.entity_embedding.is_cuda
+                and pooled_supported(model, dataset.batch_size, sampling.size)):
             fused = FusedTrainStep(model, loss.alpha)
 
         for epoch in range(self.epochs):

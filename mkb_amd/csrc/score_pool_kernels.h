@@ -1,0 +1,537 @@
+// Pooled scoring kernels (templates).  Instantiated per model in score_pool_<model>.hip, driven by score_pool.hip.
+//
+// mkb's sampler draws ONE pool of P = 2K candidate entities per batch and every row filters that same pool
+// (sampling/negative_sampling.py:166 is outside the per-row loop at :168).  So the B x K negative block of
+// compose/pipeline.py:230-232 is really "B queries x (<= P) shared candidate rows": instead of gathering
+// B*K entity rows (2.1 GB at the headline config, models/base.py:193-207) each candidate row is loaded once
+// per TILE of 8 batch rows and reused from registers.
+//
+// All three kernels use workgroups of NW waves whose lanes OWN the embedding units k (unit = one complex number
+// for RotatE, one float otherwise; KPT consecutive units per lane, NW*64*KPT >= units per row), so a workgroup
+// sees whole rows and nothing but the final table gradients ever needs an atomic:
+//   pool_fwd    workgroup = (tile of 8 batch rows, slice of the pool positions).  q[8][KPT] in registers;
+//               walks the positions used by the tile (compacted list in LDS, wave-uniform "row r uses p" bits
+//               -> scalar branches skip unused pairs).  Per position: 8 per-lane partial sums ->
+//               v_permlane32_swap / v_permlane16_swap / DPP transposed wave64 reduction (no LDS) ->
+//               NW wave totals per row staged in LDS, combined once per batch of 16 positions -> score stored
+//               directly (gamma - sum).  No atomics, bit-reproducible.
+//   pool_bwd_q  same tiling; dq[8][KPT] accumulates in registers over the slice's positions and is stored
+//               once (one partial buffer per slice).  No cross-lane traffic at all.
+//   pool_bwd_x  transposed tiling: workgroup = (tile of 8 pool positions, slice of the batch rows);
+//               x[8][KPT], dx[8][KPT] in registers, walks the rows that use the tile; dx stored once
+//               (one partial buffer per row slice).  The pair term is recomputed instead of exchanging
+//               [B,P,D] products through memory or atomics: VALU is cheaper than either here.
+// KPT = 2 / 4 lanes load float2 / float4 and give the compiler pairs of units to pack into v_pk_* ops.
+// VALU-bound by design (RotatE: one v_sqrt / v_rsq per (row, slot, complex dim)).
+#pragma once
+#include "common.h"
+#include "model_math.h"
+
+namespace mkb {
+
+constexpr int TI = 8;       // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
+constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions / rows in flight per lane)
+constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
+constexpr int kMaxP = 1024; // pool positions supported by the LDS tile lists
+constexpr int kMaxSlices = 8;
+
+struct PoolArgs {
+    const float *ent;      // [N, De]
+    const float *Q;        // [B, De] queries
+    const int64_t *pool;   // [P]
+    const uint16_t *cnt;   // [B, P] multiplicity (0 = row does not use the position)
+    const float *G;        // [B, P] d loss / d score (backward)
+    float *S;              // [B, P] scores (forward)
+    float *dQ;             // [slices, B, De] (backward, q pass)
+    float *dX;             // [slices, P, De] (backward, x pass)
+    float *g_modulus;      // pRotatE
+    const float *modulus;  // pRotatE
+    int B, P, d, x_slices;
+    int64_t De;
+    float kd, c0, c1;      // score = c0 + c1 * sum
+};
+
+// exclusive scan of a flag over the NW-wave workgroup; returns this lane's slot, *total = count.
+// Contains one barrier; callers put another one before the next call (wave_cnt is reused).
+template <int NW>
+__device__ __forceinline__ int wg_compact_slot(bool flag, int *wave_cnt, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long b = __ballot(flag);
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int c = wave_cnt[w];
+        off += (w < wave) ? c : 0;
+        tot += c;
+    }
+    *total = tot;
+    return off + __popcll(b & ((1ull << lane) - 1ull));
+}
+
+// 8 per-lane values -> wave totals via half-wave / row swaps and DPP (no LDS).  On return every lane of
+// 16-lane row R (= lane >> 4) holds t0 = total of value 4*(R>>1) + 2*(R&1) and t1 = total of that + 1.
+__device__ __forceinline__ void reduce8_wave(const float (&v)[8], float &t0, float &t1) {
+    float w[4], u[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // lanes 0-31 keep values 0-3, lanes 32-63 keep values 4-7
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+        w[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // even 16-lane rows keep j, odd rows keep j + 2
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(w[j]), __float_as_uint(w[j + 2]), false, false);
+        u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // all-reduce inside the 16-lane row: ror 8, half-mirror, two quad perms
+        float t = u[j];
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x128, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x141, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0xB1, 0xf, 0xf, false));
+        t += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(t), 0x4E, 0xf, 0xf, false));
+        u[j] = t;
+    }
+    t0 = u[0];
+    t1 = u[1];
+}
+
+// Load this lane's KPT consecutive units of a row: UNCONDITIONAL vector load from a clamped offset, then a select.
+// (A predicated load becomes a branch whose join makes the compiler wait for the data immediately, which
+// defeats the prefetch ring.)  KPT > 1 requires the row halves to be KPT*4-byte aligned (host checks).
+template <bool CP, int KPT>
+__device__ __forceinline__ void load_units(const float *__restrict__ row, int d, int NU, int u0, float (&d0)[KPT],
+                                           float (&d1)[KPT]) {
+    const bool ok = u0 < NU;  // NU is a multiple of KPT when KPT > 1: all of a lane's units are in or out together
+    const int uu = ok ? u0 : 0;
+    if constexpr (KPT == 1) {
+        const float a = row[uu];
+        const float b = CP ? row[d + uu] : 0.f;
+        d0[0] = ok ? a : 0.f;
+        d1[0] = ok ? b : 0.f;
+    } else if constexpr (KPT == 2) {
+        const float2 a = *reinterpret_cast<const float2 *>(row + uu);
+        const float2 b = CP ? *reinterpret_cast<const float2 *>(row + d + uu) : make_float2(0.f, 0.f);
+        d0[0] = ok ? a.x : 0.f; d0[1] = ok ? a.y : 0.f;
+        d1[0] = ok ? b.x : 0.f; d1[1] = ok ? b.y : 0.f;
+    } else {
+        const float4 a = *reinterpret_cast<const float4 *>(row + uu);
+        const float4 b = CP ? *reinterpret_cast<const float4 *>(row + d + uu) : make_float4(0.f, 0.f, 0.f, 0.f);
+        d0[0] = ok ? a.x : 0.f; d0[1] = ok ? a.y : 0.f; d0[2] = ok ? a.z : 0.f; d0[3] = ok ? a.w : 0.f;
+        d1[0] = ok ? b.x : 0.f; d1[1] = ok ? b.y : 0.f; d1[2] = ok ? b.z : 0.f; d1[3] = ok ? b.w : 0.f;
+    }
+}
+
+template <bool CP, int KPT>
+__device__ __forceinline__ void store_units(float *__restrict__ row, int d, int NU, int u0, const float (&s0)[KPT],
+                                            const float (&s1)[KPT]) {
+    if (u0 >= NU) return;
+    if constexpr (KPT == 1) {
+        row[u0] = s0[0];
+        if constexpr (CP) row[d + u0] = s1[0];
+    } else if constexpr (KPT == 2) {
+        *reinterpret_cast<float2 *>(row + u0) = make_float2(s0[0], s0[1]);
+        if constexpr (CP) *reinterpret_cast<float2 *>(row + d + u0) = make_float2(s1[0], s1[1]);
+    } else {
+        *reinterpret_cast<float4 *>(row + u0) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+        if constexpr (CP) *reinterpret_cast<float4 *>(row + d + u0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int MODEL, bool HEAD, int KPT, int NW>
+__global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int WG = NW * 64;
+    __shared__ int s_row[kMaxP];                // entity id per active position
+    __shared__ int s_pos[kMaxP];                // pool position
+    __shared__ unsigned s_mask[kMaxP];          // bit r: row r of the tile uses it
+    __shared__ float s_part[2][kSlab][NW][TI];  // wave totals, double buffered
+    __shared__ int s_wave_cnt[NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * TI;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = tid * KPT;
+
+    // positions used by at least one row of the tile, compacted into LDS
+    int n_act = 0;
+    for (int base = 0; base < A.P; base += WG) {
+        const int p = base + tid;
+        unsigned m_own = 0;
+        if (p < A.P) {
+            unsigned c[TI];
+#pragma unroll
+            for (int r = 0; r < TI; ++r) c[r] = (i0 + r < A.B) ? A.cnt[(int64_t)(i0 + r) * A.P + p] : 0;
+#pragma unroll
+            for (int r = 0; r < TI; ++r) m_own |= (c[r] != 0) ? (1u << r) : 0u;
+        }
+        int tot;
+        const int slot = n_act + wg_compact_slot<NW>(m_own != 0, s_wave_cnt, &tot);
+        if (m_own != 0) {
+            s_pos[slot] = p;
+            s_mask[slot] = m_own;
+            s_row[slot] = (int)A.pool[p];
+        }
+        n_act += tot;
+        __syncthreads();
+    }
+
+    float q0[TI][KPT], q1[TI][KPT];
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+        if (i0 + r >= A.B) {
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+        }
+    }
+
+    // this workgroup's slice: active positions a = slice, slice + nslices, ...
+    const int nsl = gridDim.y, sl = blockIdx.y;
+    const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
+    const int j_last = n_mine - 1;
+
+    // Candidate rows stream through a kRing-deep register ring; loads are UNCONDITIONAL (index clamped to the last
+    // position) so that the compiler can count outstanding loads instead of draining them.
+    float xr0[kRing][KPT], xr1[kRing][KPT];
+    auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
+        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
+        load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
+    };
+    if (n_mine > 0) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) load_x(min(s, j_last), xr0[s], xr1[s]);
+    }
+    for (int jb = 0; jb < n_mine; jb += kRing) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            const int jj = j % kSlab, buf = (j / kSlab) & 1;
+            const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[sl + min(j, j_last) * nsl]) : 0u;
+            float x0[KPT], x1[KPT];
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
+            load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
+            float part[TI];
+#pragma unroll
+            for (int r = 0; r < TI; ++r) {
+                part[r] = 0.f;
+                if (m & (1u << r)) {
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) {  // out-of-range units hold q = x = 0 and contribute exactly 0
+                        if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
+                        else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                    }
+                }
+            }
+            float t0, t1;
+            reduce8_wave(part, t0, t1);
+            if ((lane & 15) == 0) {
+                const int R = lane >> 4, r = 4 * (R >> 1) + 2 * (R & 1);
+                s_part[buf][jj][wave][r] = t0;
+                s_part[buf][jj][wave][r + 1] = t1;
+            }
+            if (j < n_mine && (jj == kSlab - 1 || j == j_last)) {  // wave-uniform: combine <= kSlab positions
+                __syncthreads();  // double-buffered s_part: one barrier per batch
+                const int j0 = j - jj, nb = jj + 1;
+                if (tid < nb * TI) {
+                    const int cj = tid / TI, r = tid % TI;
+                    const int a = sl + (j0 + cj) * nsl;
+                    if (s_mask[a] & (1u << r)) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) sum += s_part[buf][cj][w][r];
+                        if constexpr (MODEL == MKB_PROTATE) sum *= A.modulus[0];  // gamma - modulus * sum (protate.py:91)
+                        A.S[(int64_t)(i0 + r) * A.P + s_pos[a]] = A.c0 + A.c1 * sum;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dq
+template <int MODEL, bool HEAD, int KPT, int NW>
+__global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int WG = NW * 64;
+    __shared__ int s_row[kMaxP];
+    __shared__ unsigned s_mask[kMaxP];
+    __shared__ __attribute__((aligned(16))) float s_g[kMaxP][TI];  // gradient seeds of the tile per active position
+    __shared__ int s_wave_cnt[NW];
+    __shared__ float s_red[NW];
+
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * TI;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = tid * KPT;
+
+    int n_act = 0;
+    for (int base = 0; base < A.P; base += WG) {
+        const int p = base + tid;
+        unsigned m_own = 0;
+        float g_own[TI];
+#pragma unroll
+        for (int r = 0; r < TI; ++r) g_own[r] = 0.f;
+        if (p < A.P) {
+            unsigned c[TI];
+#pragma unroll
+            for (int r = 0; r < TI; ++r) {
+                const bool in = i0 + r < A.B;
+                c[r] = in ? A.cnt[(int64_t)(i0 + r) * A.P + p] : 0;
+                g_own[r] = in ? A.G[(int64_t)(i0 + r) * A.P + p] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < TI; ++r) m_own |= (c[r] != 0) ? (1u << r) : 0u;
+        }
+        int tot;
+        const int slot = n_act + wg_compact_slot<NW>(m_own != 0, s_wave_cnt, &tot);
+        if (m_own != 0) {
+            s_mask[slot] = m_own;
+            s_row[slot] = (int)A.pool[p];
+#pragma unroll
+            for (int r = 0; r < TI; ++r) s_g[slot][r] = g_own[r];
+        }
+        n_act += tot;
+        __syncthreads();
+    }
+
+    float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            if (i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+            dq0[r][v] = 0.f;
+            dq1[r][v] = 0.f;
+        }
+    }
+    const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
+    float extra = 0.f;
+
+    const int nsl = gridDim.y, sl = blockIdx.y;
+    const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
+    const int j_last = n_mine - 1;
+    float xr0[kRing][KPT], xr1[kRing][KPT];
+    auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
+        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
+        load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
+    };
+    if (n_mine > 0) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) load_x(min(s, j_last), xr0[s], xr1[s]);
+    }
+    for (int jb = 0; jb < n_mine; jb += kRing) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            const int a = sl + min(j, j_last) * nsl;
+            const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[a]) : 0u;
+            float g[TI];
+#pragma unroll
+            for (int r = 0; r < TI; ++r) g[r] = s_g[a][r];  // two ds_read_b128, same address in every lane
+            float x0[KPT], x1[KPT];
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
+            load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
+#pragma unroll
+            for (int r = 0; r < TI; ++r) {
+                if (m & (1u << r)) {
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) {
+                        if constexpr (CP) {
+                            Cplx dq, dx;
+                            pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
+                            dq0[r][v] += dq.re;
+                            dq1[r][v] += dq.im;
+                        } else {
+                            float dq, dx, e0 = 0.f;
+                            pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
+                            dq0[r][v] += dq;
+                            extra += g[r] * e0;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float *dQs = A.dQ + (int64_t)sl * A.B * A.De;
+#pragma unroll
+    for (int r = 0; r < TI; ++r)
+        if (i0 + r < A.B) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
+    if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
+        extra = wave_sum(extra);
+        if ((tid & 63) == 0) s_red[tid >> 6] = extra;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += s_red[w];
+            atomicAdd(A.g_modulus, -s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dx
+template <int MODEL, bool HEAD, int KPT, int NW>
+__global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int WG = NW * 64;
+    constexpr int kMaxRows = 1024;       // rows per slice (host picks the slice count accordingly)
+    __shared__ int s_i[kMaxRows];        // batch rows of the slice that use the position tile
+    __shared__ unsigned s_mask[kMaxRows];// bit t: the row uses position p0 + t
+    __shared__ __attribute__((aligned(16))) float s_g[kMaxRows][TI];
+    __shared__ int s_wave_cnt[NW];
+
+    const int tid = threadIdx.x;
+    // 1-D grid, tile-major: the workgroups of the low position tiles (used by every row: the heavy ones) are
+    // dispatched first; the light / empty tiles fill in behind them.
+    const int nsl = A.x_slices, sl = blockIdx.x % nsl;
+    const int p0 = (blockIdx.x / nsl) * TI;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = tid * KPT;
+    const int rows_per = (A.B + nsl - 1) / nsl;  // <= kMaxRows
+    const int r_lo = sl * rows_per, r_hi = min(A.B, r_lo + rows_per);
+
+    int n_rows = 0;
+    for (int base = r_lo; base < r_hi; base += WG) {
+        const int i_own = base + tid;
+        unsigned m_own = 0;
+        float g_own[TI];
+#pragma unroll
+        for (int t = 0; t < TI; ++t) g_own[t] = 0.f;
+        if (i_own < r_hi) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                if (p0 + t < A.P) {
+                    const unsigned c = A.cnt[(int64_t)i_own * A.P + p0 + t];
+                    g_own[t] = A.G[(int64_t)i_own * A.P + p0 + t];
+                    m_own |= (c != 0) ? (1u << t) : 0u;
+                }
+            }
+        }
+        int tot;
+        const int slot = n_rows + wg_compact_slot<NW>(m_own != 0, s_wave_cnt, &tot);
+        if (m_own != 0) {
+            s_i[slot] = i_own;
+            s_mask[slot] = m_own;
+#pragma unroll
+            for (int t = 0; t < TI; ++t) s_g[slot][t] = g_own[t];
+        }
+        n_rows += tot;
+        __syncthreads();
+    }
+
+    float x0[TI][KPT], x1[TI][KPT], dx0[TI][KPT], dx1[TI][KPT];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+        const bool pin = (p0 + t < A.P) && n_rows > 0;
+        load_units<CP, KPT>(A.ent + (pin ? A.pool[p0 + t] : 0) * A.De, A.d, NU, u0, x0[t], x1[t]);
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            if (!pin) { x0[t][v] = 0.f; x1[t][v] = 0.f; }
+            dx0[t][v] = 0.f;
+            dx1[t][v] = 0.f;
+        }
+    }
+    const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
+
+    float qr0[kRing][KPT], qr1[kRing][KPT];
+    auto load_q = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
+        const float *q = A.Q + (int64_t)__builtin_amdgcn_readfirstlane(s_i[j]) * A.De;
+        load_units<CP, KPT>(q, A.d, NU, u0, d0, d1);
+    };
+    const int j_last = n_rows - 1;
+    if (n_rows > 0) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) load_q(min(s, j_last), qr0[s], qr1[s]);
+    }
+    for (int jb = 0; jb < n_rows; jb += kRing) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) {
+            const int j = jb + s;
+            const int jc = min(j, j_last);
+            const unsigned m = (j < n_rows) ? __builtin_amdgcn_readfirstlane(s_mask[jc]) : 0u;
+            float g[TI];
+#pragma unroll
+            for (int t = 0; t < TI; ++t) g[t] = s_g[jc][t];
+            float q0[KPT], q1[KPT];
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { q0[v] = qr0[s][v]; q1[v] = qr1[s][v]; }
+            load_q(min(j + kRing, j_last), qr0[s], qr1[s]);
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                if (m & (1u << t)) {
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) {
+                        if constexpr (CP) {
+                            Cplx dq, dx;
+                            pair_bwd_cmod(Cplx{q0[v], q1[v]}, Cplx{x0[t][v], x1[t][v]}, g[t], dq, dx);
+                            dx0[t][v] += dx.re;
+                            dx1[t][v] += dx.im;
+                        } else {
+                            float dq, dx, e0 = 0.f;
+                            pair_bwd_real<MODEL, HEAD>(q0[v], x0[t][v], g[t], A.kd, modulus, dq, dx, e0);
+                            dx0[t][v] += dx;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float *dXs = A.dX + (int64_t)sl * A.P * A.De;
+#pragma unroll
+    for (int t = 0; t < TI; ++t)
+        if (p0 + t < A.P) store_units<CP, KPT>(dXs + (int64_t)(p0 + t) * A.De, A.d, NU, u0, dx0[t], dx1[t]);
+}
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+struct PoolLaunch {
+    int kpt, nw;          // units per lane, waves per workgroup
+    int fwd_slices, q_slices, x_slices;
+};
+
+// Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd_q, 2 bwd_x*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+                              hipStream_t st);
+int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
+int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
+int pool_launch_complex(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
+int pool_launch_distmult(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
+int pool_launch_protate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
+
+template <int MODEL, bool HEAD, int KPT, int NW>
+static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+    const dim3 block(NW * 64);
+    if (which == 0) {
+        dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.fwd_slices);
+        hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+    } else if (which == 1) {
+        dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.q_slices);
+        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+    } else {
+        dim3 grid((unsigned)(((A.P + TI - 1) / TI) * L.x_slices));
+        hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+    }
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+template <int MODEL, bool HEAD>
+static int launch_head(int which, const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+    if (L.kpt == 1 && L.nw == 4) return launch_cfg<MODEL, HEAD, 1, 4>(which, L, A, st);
+    if (L.kpt == 1 && L.nw == 16) return launch_cfg<MODEL, HEAD, 1, 16>(which, L, A, st);
+    if (L.kpt == 2 && L.nw == 8) return launch_cfg<MODEL, HEAD, 2, 8>(which, L, A, st);
+    if (L.kpt == 2 && L.nw == 16) return launch_cfg<MODEL, HEAD, 2, 16>(which, L, A, st);
+    if (L.kpt == 4 && L.nw == 16) return launch_cfg<MODEL, HEAD, 4, 16>(which, L, A, st);
+    return set_error(MKB_ERR_UNSUPPORTED, "no pooled kernel configuration (kpt=%d, nw=%d)", L.kpt, L.nw);
+}
+
+#define MKB_DEFINE_POOL_LAUNCH(fn, MODEL)                                                                       \
+    int fn(int which, bool head, const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {                      \
+        return head ? launch_head<MODEL, true>(which, L, A, st) : launch_head<MODEL, false>(which, L, A, st); \
+    }
+
+}  // namespace mkb

@@ -94,6 +94,10 @@ class Evaluation:
         if self._device_ok(model) and not getattr(self, "force_reference_path", False):
             with torch.no_grad():
                 for mode in ("head-batch", "tail-batch"):  # same order as get_entity_stream
+                    # The reference creates one DataLoader iterator per side here, and each creation draws one int64
+                    # from torch's global CPU generator (the workers' base seed).  Draw it too, so that a training
+                    # run interleaved with evaluations keeps shuffling its batches exactly like the reference.
+                    torch.empty((), dtype=torch.int64).random_()
                     for ranking in self.ranks(model, dataset, mode).tolist():
                         metrics["MRR"].update(1.0 / ranking)
                         metrics["MR"].update(ranking)

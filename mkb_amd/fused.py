@@ -13,7 +13,7 @@ import torch
 from . import _hip
 from .sampling.negative_sampling import PoolInfo
 
-__all__ = ["FusedTrainStep", "pooled_forward"]
+__all__ = ["FusedTrainStep", "pooled_forward", "pooled_supported"]
 
 _workspaces = {}
 
@@ -32,8 +32,9 @@ def _workspace(model, B, K):
     return ws
 
 
-def _supported(K):
-    return 2 * K <= 1024
+def pooled_supported(model, B, K):
+    """True if the pooled kernels cover this table shape / batch (else the general kernels are used)."""
+    return bool(_hip.lib().mkb_pool_supported(model._tables(), B, K))
 
 
 class _PoolScoreFn(torch.autograd.Function):
@@ -76,7 +77,6 @@ def pooled_forward(model, sample, info, mode_id):
 
 
 PoolInfo.enabled = True
-PoolInfo.supported = staticmethod(_supported)
 
 
 class FusedTrainStep:

@@ -73,7 +73,8 @@ class PoolInfo:
         self.sample_ptr, self.batch = sample.data_ptr(), sample.shape[0]
 
     def usable_for(self, model, sample, mode_id):
-        return (self.enabled and 2 * self.size <= 1024 and mode_id == self.mode_id and sample.shape[0] == self.batch
+        return (self.enabled and mode_id == self.mode_id and sample.shape[0] == self.batch
+                and _hip.lib().mkb_pool_supported(model._tables(), self.batch, self.size)
                 and sample.data_ptr() == self.sample_ptr and self.pool.device == model.entity_embedding.device)
 
 
