@@ -29,11 +29,25 @@ namespace mkb {
 
 constexpr int MT_N = 624, MT_M = 397;
 
+// One filter dictionary (negative_sampling.py:7-28) on the device: an open-addressing hash table whose entries
+// carry everything a row needs in ONE 32-byte load (no dependent key -> offsets -> flags chain), the concatenated
+// sorted true sets, and an entity bitmap for every set of kBitmapMin+ elements (the 3,612-head sets of FB15k-237's
+// hub tails made their rows -- and therefore the whole kernel -- 3x slower when streamed element by element).
+struct HEntry {
+    int64_t key;      // -1 = empty slot
+    int64_t off;      // start of the set in `values`
+    int32_t len;      // elements in the set
+    int32_t flags;    // bit 0: np.in1d takes its sort path for this set; bits 1..: 1 + bitmap index (0 = no bitmap)
+    int64_t pad;
+};
+constexpr int kBitmapMin = 128;
+
 struct Csr {
-    int64_t *keys = nullptr, *offsets = nullptr, *values = nullptr;
-    uint8_t *sortflag = nullptr;
-    int32_t *htab = nullptr;  // open-addressing hash: slot -> key index or -1 (capacity = pow2 >= 2 nk)
+    HEntry *htab = nullptr;   // capacity = pow2 >= 2 nk
+    int64_t *values = nullptr;
+    uint32_t *bitmaps = nullptr;  // [n_bitmaps][bm_words]
     uint32_t hmask = 0;
+    int bm_words = 0;
     int64_t nk = 0;
 };
 
@@ -238,22 +252,37 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
     if (valid) {
         const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
         const int64_t key = head_mode ? r * key_stride + t : h * key_stride + r;
-        int64_t ki = -1;
+        HEntry ent{-1, 0, 0, 0, 0};
         if (csr.nk > 0) {
             uint32_t slot = (uint32_t)mix64((uint64_t)key) & csr.hmask;
             for (;;) {
-                const int32_t idx = csr.htab[slot];
-                if (idx < 0) break;
-                if (csr.keys[idx] == key) { ki = idx; break; }
+                ent = csr.htab[slot];
+                if (ent.key == key || ent.key < 0) break;
                 slot = (slot + 1) & csr.hmask;
             }
         }
-        found = ki >= 0;
+        found = ent.key == key;
         if (found) {
-            const int64_t off = csr.offsets[ki];
-            const int m = (int)(csr.offsets[ki + 1] - off);
-            const int64_t *rec = csr.values + off;
-            const bool sortpath = csr.sortflag[ki] != 0;
+            const int m = ent.len;
+            const int64_t *rec = csr.values + ent.off;
+            const bool sortpath = ent.flags & 1;
+            const int bm = (ent.flags >> 1) - 1;
+            if (bm >= 0) {  // big set: one independent bitmap probe per pool entry
+                const uint32_t *bits = csr.bitmaps + (size_t)bm * csr.bm_words;
+                for (int base = 0; base < P; base += 64) {
+                    const int p = base + lane;
+                    bool mem = false;
+                    if (p < P) {
+                        const int64_t c = pool[p];
+                        mem = (bits[c >> 5] >> (c & 31)) & 1u;
+                    }
+                    const unsigned long long b = __ballot(mem);
+                    if (lane == 0) {
+                        member[base >> 5] = (uint32_t)b;
+                        if ((base >> 5) + 1 < words) member[(base >> 5) + 1] = (uint32_t)(b >> 32);
+                    }
+                }
+            } else
             // Stream the true set 8 elements per lane at a time (independent coalesced loads in flight together),
             // probe a Bloom bitmap of the pool first: almost every element misses and costs one LDS read; the
             // rare hit is confirmed (and its positions found) by binary search in the sorted pool.
@@ -326,47 +355,49 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
 }
 
 static int upload_csr(Csr &c, const int64_t *keys, int64_t nk, const int64_t *offsets, const int64_t *values, int64_t P,
-                      hipStream_t st) {
+                      int64_t n_entity, hipStream_t st) {
     MKB_REQUIRE(nk >= 0 && nk < (1ll << 30) && (nk == 0 || (keys && offsets && values)), "bad CSR");
     c.nk = nk;
     const int64_t nv = nk ? offsets[nk] : 0;
-    std::vector<uint8_t> flag((size_t)(nk ? nk : 1), 0);
     const double loop_thr = 10.0 * pow((double)P, 0.145);  // numpy: len(ar2) < 10 * len(ar1) ** 0.145
-    for (int64_t k = 0; k < nk; ++k) {
-        const int64_t m = offsets[k + 1] - offsets[k];
-        MKB_REQUIRE(m > 0, "empty true-set for key %lld", (long long)k);
-        const int64_t range = values[offsets[k + 1] - 1] - values[offsets[k]];
-        const bool table = range <= 6 * (P + m);
-        const bool loop = (double)m < loop_thr;
-        flag[(size_t)k] = (!table && !loop) ? 1 : 0;
-    }
-    MKB_CHECK_HIP(hipMalloc(&c.keys, sizeof(int64_t) * (size_t)(nk ? nk : 1)));
-    MKB_CHECK_HIP(hipMalloc(&c.offsets, sizeof(int64_t) * (size_t)(nk + 1)));
-    MKB_CHECK_HIP(hipMalloc(&c.values, sizeof(int64_t) * (size_t)(nv ? nv : 1)));
-    MKB_CHECK_HIP(hipMalloc(&c.sortflag, (size_t)(nk ? nk : 1)));
     uint32_t cap = 2;
     while ((int64_t)cap < 2 * nk) cap <<= 1;
-    std::vector<int32_t> htab(cap, -1);
+    std::vector<HEntry> htab(cap, HEntry{-1, 0, 0, 0, 0});
     c.hmask = cap - 1;
+    c.bm_words = (int)((n_entity + 31) / 32);
+    std::vector<uint32_t> bitmaps;
+    int n_bm = 0;
     for (int64_t k = 0; k < nk; ++k) {
+        const int64_t m = offsets[k + 1] - offsets[k];
+        MKB_REQUIRE(m > 0 && m < INT32_MAX, "bad true-set size for key %lld", (long long)k);
+        const int64_t range = values[offsets[k + 1] - 1] - values[offsets[k]];
+        const bool table = range <= 6 * (P + m);   // numpy >= 1.24 _in1d: table / loop / sort path selection
+        const bool loop = (double)m < loop_thr;
+        int32_t flags = (!table && !loop) ? 1 : 0;
+        if (m >= kBitmapMin && (int64_t)(n_bm + 1) * c.bm_words * 4 <= (256ll << 20)) {
+            bitmaps.resize((size_t)(n_bm + 1) * c.bm_words, 0u);
+            uint32_t *b = bitmaps.data() + (size_t)n_bm * c.bm_words;
+            for (int64_t e = offsets[k]; e < offsets[k + 1]; ++e) b[values[e] >> 5] |= 1u << (values[e] & 31);
+            flags |= (n_bm + 1) << 1;
+            ++n_bm;
+        }
         uint32_t slot = (uint32_t)mix64((uint64_t)keys[k]) & c.hmask;
-        while (htab[slot] >= 0) slot = (slot + 1) & c.hmask;
-        htab[slot] = (int32_t)k;
+        while (htab[slot].key >= 0) slot = (slot + 1) & c.hmask;
+        htab[slot] = HEntry{keys[k], offsets[k], (int32_t)m, flags, 0};
     }
-    MKB_CHECK_HIP(hipMalloc(&c.htab, sizeof(int32_t) * cap));
-    MKB_CHECK_HIP(hipMemcpyAsync(c.htab, htab.data(), sizeof(int32_t) * cap, hipMemcpyHostToDevice, st));
-    if (nk) {
-        MKB_CHECK_HIP(hipMemcpyAsync(c.keys, keys, sizeof(int64_t) * (size_t)nk, hipMemcpyHostToDevice, st));
-        MKB_CHECK_HIP(hipMemcpyAsync(c.offsets, offsets, sizeof(int64_t) * (size_t)(nk + 1), hipMemcpyHostToDevice, st));
-        MKB_CHECK_HIP(hipMemcpyAsync(c.values, values, sizeof(int64_t) * (size_t)nv, hipMemcpyHostToDevice, st));
-        MKB_CHECK_HIP(hipMemcpyAsync(c.sortflag, flag.data(), (size_t)nk, hipMemcpyHostToDevice, st));
-    }
+    MKB_CHECK_HIP(hipMalloc(&c.htab, sizeof(HEntry) * cap));
+    MKB_CHECK_HIP(hipMalloc(&c.values, sizeof(int64_t) * (size_t)(nv ? nv : 1)));
+    MKB_CHECK_HIP(hipMalloc(&c.bitmaps, sizeof(uint32_t) * (bitmaps.empty() ? 1 : bitmaps.size())));
+    MKB_CHECK_HIP(hipMemcpyAsync(c.htab, htab.data(), sizeof(HEntry) * cap, hipMemcpyHostToDevice, st));
+    if (nv) MKB_CHECK_HIP(hipMemcpyAsync(c.values, values, sizeof(int64_t) * (size_t)nv, hipMemcpyHostToDevice, st));
+    if (!bitmaps.empty())
+        MKB_CHECK_HIP(hipMemcpyAsync(c.bitmaps, bitmaps.data(), sizeof(uint32_t) * bitmaps.size(), hipMemcpyHostToDevice, st));
     MKB_CHECK_HIP(hipStreamSynchronize(st));  // host vectors die at return
     return MKB_OK;
 }
 
 static void free_csr(Csr &c) {
-    (void)hipFree(c.keys); (void)hipFree(c.offsets); (void)hipFree(c.values); (void)hipFree(c.sortflag); (void)hipFree(c.htab);
+    (void)hipFree(c.htab); (void)hipFree(c.values); (void)hipFree(c.bitmaps);
     c = Csr();
 }
 
@@ -403,8 +434,8 @@ extern "C" int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t
         sd = 1812433253u * (sd ^ (sd >> 30)) + (uint32_t)i + 1u;
     }
     if (int rc = mkb_sampler_set_state(s, key, MT_N, stream)) return fail(rc);
-    if (int rc = upload_csr(s->head, head_keys_host, n_head_keys, head_offsets_host, head_values_host, 2 * K, st)) return fail(rc);
-    if (int rc = upload_csr(s->tail, tail_keys_host, n_tail_keys, tail_offsets_host, tail_values_host, 2 * K, st)) return fail(rc);
+    if (int rc = upload_csr(s->head, head_keys_host, n_head_keys, head_offsets_host, head_values_host, 2 * K, n_entity, st)) return fail(rc);
+    if (int rc = upload_csr(s->tail, tail_keys_host, n_tail_keys, tail_offsets_host, tail_values_host, 2 * K, n_entity, st)) return fail(rc);
     *out = s;
     return MKB_OK;
 }

@@ -218,11 +218,20 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
 #pragma unroll
             for (int r = 0; r < TI; ++r) {
                 part[r] = 0.f;
-                if (m & (1u << r)) {
+                if (m & (1u << r)) {  // out-of-range units hold q = x = 0 and contribute exactly 0
+                    if constexpr (CP && KPT % 2 == 0) {
+                        f2 acc = f2{0.f, 0.f};
 #pragma unroll
-                    for (int v = 0; v < KPT; ++v) {  // out-of-range units hold q = x = 0 and contribute exactly 0
-                        if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
-                        else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                        for (int v = 0; v < KPT; v += 2)
+                            acc += pair_term_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
+                                                   f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]});
+                        part[r] = acc.x + acc.y;
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
+                            else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                        }
                     }
                 }
             }
@@ -340,6 +349,16 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
 #pragma unroll
             for (int r = 0; r < TI; ++r) {
                 if (m & (1u << r)) {
+                    if constexpr (CP && KPT % 2 == 0) {
+#pragma unroll
+                        for (int v = 0; v < KPT; v += 2) {
+                            f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
+                            pair_bwd_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]}, f2{x0[v], x0[v + 1]},
+                                           f2{x1[v], x1[v + 1]}, g[r], ar, ai);
+                            dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
+                            dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
+                        }
+                    } else
 #pragma unroll
                     for (int v = 0; v < KPT; ++v) {
                         if constexpr (CP) {
@@ -464,6 +483,16 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
 #pragma unroll
             for (int t = 0; t < TI; ++t) {
                 if (m & (1u << t)) {
+                    if constexpr (CP && KPT % 2 == 0) {  // accumulates -dx (the dq sign); negated once at the store
+#pragma unroll
+                        for (int v = 0; v < KPT; v += 2) {
+                            f2 ar = f2{dx0[t][v], dx0[t][v + 1]}, ai = f2{dx1[t][v], dx1[t][v + 1]};
+                            pair_bwd_cmod2(f2{q0[v], q0[v + 1]}, f2{q1[v], q1[v + 1]}, f2{x0[t][v], x0[t][v + 1]},
+                                           f2{x1[t][v], x1[t][v + 1]}, g[t], ar, ai);
+                            dx0[t][v] = ar.x; dx0[t][v + 1] = ar.y;
+                            dx1[t][v] = ai.x; dx1[t][v + 1] = ai.y;
+                        }
+                    } else
 #pragma unroll
                     for (int v = 0; v < KPT; ++v) {
                         if constexpr (CP) {
@@ -483,8 +512,13 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
     }
     float *dXs = A.dX + (int64_t)sl * A.P * A.De;
 #pragma unroll
-    for (int t = 0; t < TI; ++t)
+    for (int t = 0; t < TI; ++t) {
+        if constexpr (CP && KPT % 2 == 0) {
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { dx0[t][v] = -dx0[t][v]; dx1[t][v] = -dx1[t][v]; }
+        }
         if (p0 + t < A.P) store_units<CP, KPT>(dXs + (int64_t)(p0 + t) * A.De, A.d, NU, u0, dx0[t], dx1[t]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
