@@ -72,6 +72,129 @@ __global__ __launch_bounds__(256) void query_bwd_kernel(RowArgs A) {
     }
 }
 
+// ---- fused row kernels of the training step --------------------------------------------------------------
+// One workgroup per batch row, lanes own units.  They replace four launches of the step (general forward and
+// backward for the positive triple, query build, query backward) by two, read h / r / t rows once, and merge
+// the positive- and negative-path contributions to the same table row before the (single) atomic per element.
+struct RowStepArgs {
+    const float *ent, *rel, *modulus;
+    const int64_t *sample;
+    float *Q;                 // [B, De] negative-path queries (out of row_fwd)
+    const float *dQ;          // [nslices, B, De] partials (in of row_bwd)
+    float *pos_score;         // [B] out of row_fwd
+    const float *dpos;        // [B] d loss / d pos_score (in of row_bwd)
+    float *g_ent, *g_rel, *g_modulus;
+    int64_t De, Dr;
+    int d, B, nslices;
+    float kd, gamma;
+};
+
+__device__ __forceinline__ float block_sum_256_row(float v, float *red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// positive score (mode None == tail-style formula against the true tail, pipeline.py:211) + Q for the negatives
+template <int MODEL, bool HEAD>
+__global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
+    __shared__ float red[4];
+    const int64_t i = blockIdx.x;
+    const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
+    const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
+    float *q = A.Q + i * A.De;
+    float acc = 0.f;
+    if constexpr (ModelTraits<MODEL>::cplx_query) {
+        for (int u = threadIdx.x; u < A.d; u += 256) {
+            const Cplx ch{eh[u], eh[A.d + u]}, ct{et[u], et[A.d + u]};
+            const Cplx cr{er[u], MODEL == MKB_COMPLEX ? er[A.d + u] : 0.f};
+            const Cplx qp = build_q_cplx<MODEL, false>(ch, cr, A.kd);
+            const Cplx qn = HEAD ? build_q_cplx<MODEL, true>(ct, cr, A.kd) : qp;
+            q[u] = qn.re;
+            q[A.d + u] = qn.im;
+            if constexpr (ModelTraits<MODEL>::cplx_pair) acc += pair_term_cmod(qp, ct);
+            else acc += pair_term_real<MODEL, false>(qp.re, ct.re, A.kd) + pair_term_real<MODEL, false>(qp.im, ct.im, A.kd);
+        }
+    } else {
+        for (int u = threadIdx.x; u < (int)A.De; u += 256) {
+            const float vh = eh[u], vr = er[u], vt = et[u];
+            const float qp = build_q_real<MODEL, false>(vh, vr, A.kd);
+            q[u] = HEAD ? build_q_real<MODEL, true>(vr, vt, A.kd) : qp;
+            acc += pair_term_real<MODEL, false>(qp, vt, A.kd);
+        }
+    }
+    acc = block_sum_256_row(acc, red);
+    if (threadIdx.x == 0) A.pos_score[i] = finish_score<MODEL>(acc, A.gamma, MODEL == MKB_PROTATE ? A.modulus[0] : 0.f);
+}
+
+// backward of the positive pair + chain of both query gradients into the rows of h, r, t
+template <int MODEL, bool HEAD>
+__global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
+    __shared__ float red[4];
+    const int64_t i = blockIdx.x;
+    const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
+    const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
+    float *g_h = A.g_ent + h * A.De, *g_r = A.g_rel + r * A.Dr, *g_t = A.g_ent + t * A.De;
+    const float *dq = A.dQ + i * A.De;
+    const int64_t sstride = (int64_t)A.B * A.De;
+    const float gp = A.dpos[i];
+    const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
+    auto dq_at = [&](int k) {
+        float s = 0.f;
+        for (int sl = 0; sl < A.nslices; ++sl) s += dq[sl * sstride + k];
+        return s;
+    };
+    float extra = 0.f;
+    if constexpr (ModelTraits<MODEL>::cplx_query) {
+        for (int u = threadIdx.x; u < A.d; u += 256) {
+            const Cplx ch{eh[u], eh[A.d + u]}, ct{et[u], et[A.d + u]};
+            const Cplx cr{er[u], MODEL == MKB_COMPLEX ? er[A.d + u] : 0.f};
+            // positive pair: q = h (x) rot, candidate = t
+            const Cplx qp = build_q_cplx<MODEL, false>(ch, cr, A.kd);
+            Cplx dqp, dxp;
+            if constexpr (ModelTraits<MODEL>::cplx_pair) {
+                pair_bwd_cmod(qp, ct, gp, dqp, dxp);
+            } else {
+                float e0 = 0.f;
+                pair_bwd_real<MODEL, false>(qp.re, ct.re, gp, A.kd, modulus, dqp.re, dxp.re, e0);
+                pair_bwd_real<MODEL, false>(qp.im, ct.im, gp, A.kd, modulus, dqp.im, dxp.im, e0);
+            }
+            Cplx dh, dr, dt = dxp, de, dr2;
+            query_bwd_cplx<MODEL, false>(ch, cr, dqp, A.kd, dh, dr);
+            // negative path: q = conj(rot) (x) t (head-batch) or h (x) rot (tail-batch)
+            const Cplx dqn{dq_at(u), dq_at(A.d + u)};
+            query_bwd_cplx<MODEL, HEAD>(HEAD ? ct : ch, cr, dqn, A.kd, de, dr2);
+            if constexpr (HEAD) { dt.re += de.re; dt.im += de.im; } else { dh.re += de.re; dh.im += de.im; }
+            dr.re += dr2.re; dr.im += dr2.im;
+            atomicAdd(g_h + u, dh.re); atomicAdd(g_h + A.d + u, dh.im);
+            atomicAdd(g_t + u, dt.re); atomicAdd(g_t + A.d + u, dt.im);
+            atomicAdd(g_r + u, dr.re);
+            if constexpr (MODEL == MKB_COMPLEX) atomicAdd(g_r + A.d + u, dr.im);
+        }
+    } else {
+        for (int u = threadIdx.x; u < (int)A.De; u += 256) {
+            const float vh = eh[u], vr = er[u], vt = et[u];
+            const float qp = build_q_real<MODEL, false>(vh, vr, A.kd);
+            float dqp, dxp, e0 = 0.f;
+            pair_bwd_real<MODEL, false>(qp, vt, gp, A.kd, modulus, dqp, dxp, e0);
+            extra += gp * e0;
+            float dh, dr, dt = dxp;
+            query_bwd_real<MODEL, false>(vh, vr, dqp, A.kd, dh, dr);  // tail-style: a = h, b = r
+            float da, db;
+            query_bwd_real<MODEL, HEAD>(HEAD ? vr : vh, HEAD ? vt : vr, dq_at(u), A.kd, da, db);
+            if constexpr (HEAD) { dr += da; dt += db; } else { dh += da; dr += db; }
+            atomicAdd(g_h + u, dh);
+            atomicAdd(g_r + u, dr);
+            atomicAdd(g_t + u, dt);
+        }
+    }
+    if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z| for the positive pair
+        extra = block_sum_256_row(extra, red);
+        if (threadIdx.x == 0) atomicAdd(A.g_modulus, -extra);
+    }
+}
+
 // g_ent[pool[p]] += sum over slices of dX[slice][p]   (pool positions may repeat an entity: atomics)
 __global__ __launch_bounds__(256) void pool_scatter_kernel(const float *__restrict__ dX, int nslices, int P,
                                                            const int64_t *__restrict__ pool, float *__restrict__ g_ent,
@@ -173,6 +296,20 @@ static int run_query_bwd(const RowArgs &ra, int64_t B, hipStream_t st) {
     return MKB_OK;
 }
 
+template <int MODEL, bool HEAD>
+static int run_row_fwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
+    hipLaunchKernelGGL((row_fwd_kernel<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+template <int MODEL, bool HEAD>
+static int run_row_bwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
+    hipLaunchKernelGGL((row_bwd_kernel<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 #define MKB_DISPATCH(fn, model, head, ...)                                                            \
     switch (model) {                                                                                  \
         case MKB_TRANSE: return (head) ? fn<MKB_TRANSE, true>(__VA_ARGS__) : fn<MKB_TRANSE, false>(__VA_ARGS__);       \
@@ -190,11 +327,21 @@ static int dispatch_query_bwd(const mkb_tables_t *tb, bool head, const RowArgs &
     MKB_DISPATCH(run_query_bwd, tb->model, head, ra, B, st);
 }
 
+static int dispatch_row_fwd(const mkb_tables_t *tb, bool head, const RowStepArgs &ra, int64_t B, hipStream_t st) {
+    MKB_DISPATCH(run_row_fwd, tb->model, head, ra, B, st);
+}
+static int dispatch_row_bwd(const mkb_tables_t *tb, bool head, const RowStepArgs &ra, int64_t B, hipStream_t st) {
+    MKB_DISPATCH(run_row_bwd, tb->model, head, ra, B, st);
+}
+
 static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
-                      int64_t B, int64_t P, float *S, const Workspace &w, const PoolLaunch &L, hipStream_t st) {
-    RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, 1,
-               tb->phase_div};
-    if (int rc = dispatch_query_build(tb, head, ra, B, st)) return rc;
+                      int64_t B, int64_t P, float *S, const Workspace &w, const PoolLaunch &L, hipStream_t st,
+                      bool build_queries = true) {
+    if (build_queries) {
+        RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B,
+                   1, tb->phase_div};
+        if (int rc = dispatch_query_build(tb, head, ra, B, st)) return rc;
+    }
     MKB_CHECK_HIP(hipMemsetAsync(S, 0, (size_t)B * P * 4, st));
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
     A.S = S;
@@ -203,7 +350,8 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
 }
 
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
-                      const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st) {
+                      const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
+                      bool chain_queries = true) {
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
     A.g_modulus = gr->g_modulus;
     {
@@ -214,9 +362,11 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
         ProfScope ps(MKB_PROF_POOL_BWD_X, st);
         if (int rc = launcher_of(tb->model)(2, head, L, A, st)) return rc;
     }
-    RowArgs ra{tb->ent, tb->rel, sample, w.dQ, gr->g_ent, gr->g_rel, tb->entity_dim, tb->relation_dim, tb->hidden_dim,
-               (int)B, L.q_slices, tb->phase_div};
-    if (int rc = dispatch_query_bwd(tb, head, ra, B, st)) return rc;
+    if (chain_queries) {
+        RowArgs ra{tb->ent, tb->rel, sample, w.dQ, gr->g_ent, gr->g_rel, tb->entity_dim, tb->relation_dim, tb->hidden_dim,
+                   (int)B, L.q_slices, tb->phase_div};
+        if (int rc = dispatch_query_bwd(tb, head, ra, B, st)) return rc;
+    }
     hipLaunchKernelGGL(pool_scatter_kernel, dim3((unsigned)P), dim3(256), 0, st, w.dX, L.x_slices, (int)P, pool, gr->g_ent,
                        tb->entity_dim);
     MKB_LAUNCH_CHECK();
@@ -290,13 +440,19 @@ extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, cons
     const Workspace w = carve(ws, B, P, tb->entity_dim, L);
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode_is_head(mode);
-    // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211)
-    if (int rc = mkb_score_fwd(tb, sample, nullptr, B, 1, MKB_MODE_DEFAULT, pos_score, stream)) return rc;
+    RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, pos_score, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
+                   tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
+    // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
+    {
+        ProfScope ps(MKB_PROF_GENERAL_FWD, st);
+        if (int rc = dispatch_row_fwd(tb, head, ra, B, st)) return rc;
+    }
     // negative pass over the shared pool (pipeline.py:230-232)
-    if (int rc = pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st)) return rc;
+    if (int rc = pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false)) return rc;
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
     if (int rc = mkb_adversarial(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, stream)) return rc;
-    // backward (pipeline.py:236): pooled negatives, then the positives through the general kernel
-    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st)) return rc;
-    return mkb_score_bwd(tb, gr, sample, nullptr, B, 1, MKB_MODE_DEFAULT, w.dpos, stream);
+    // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
+    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false)) return rc;
+    ProfScope ps(MKB_PROF_GENERAL_BWD, st);
+    return dispatch_row_bwd(tb, head, ra, B, st);
 }
