@@ -33,12 +33,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HIDDEN, K, B, GAMMA, ALPHA, LR = 1000, 256, 1024, 9.0, 1.0, 5e-5
+MODEL, DATASET = "RotatE", "fb15k237"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+# BASELINE.json configs; the default (and the only one the driver runs) is the headline, configs[2]
+CONFIGS = {
+    "headline": dict(MODEL="RotatE", DATASET="fb15k237", HIDDEN=1000, K=256, B=1024, GAMMA=9.0, ALPHA=1.0, LR=5e-5),
+    "umls-transe": dict(MODEL="TransE", DATASET="umls", HIDDEN=64, K=16, B=256, GAMMA=6.0, ALPHA=1.0, LR=1e-3),
+    "wn18rr-rotate": dict(MODEL="RotatE", DATASET="wn18rr", HIDDEN=500, K=128, B=1024, GAMMA=6.0, ALPHA=0.5, LR=5e-5),
+    "fb15k237-complex": dict(MODEL="ComplEx", DATASET="fb15k237", HIDDEN=1000, K=256, B=1024, GAMMA=9.0, ALPHA=1.0, LR=5e-5),
+    "fb15k237-transe": dict(MODEL="TransE", DATASET="fb15k237", HIDDEN=1000, K=256, B=1024, GAMMA=9.0, ALPHA=1.0, LR=5e-5),
+    "fb15k237-distmult": dict(MODEL="DistMult", DATASET="fb15k237", HIDDEN=1000, K=256, B=1024, GAMMA=9.0, ALPHA=1.0, LR=5e-5),
+}
 
 
 def load_fb15k237():
-    z = np.load(os.path.join(ROOT, "mkb_amd", "datasets", "data", "fb15k237.npz"))
-    return z["train"].astype(np.int64), 14541, 237
+    z = np.load(os.path.join(ROOT, "mkb_amd", "datasets", "data", f"{DATASET}.npz"))
+    tr = z["train"].astype(np.int64)
+    n_ent = int(max(z["train"][:, [0, 2]].max(), z["valid"][:, [0, 2]].max(), z["test"][:, [0, 2]].max())) + 1
+    n_rel = int(max(z["train"][:, 1].max(), z["valid"][:, 1].max(), z["test"][:, 1].max())) + 1
+    if DATASET == "fb15k237":
+        n_ent, n_rel = 14541, 237
+    return tr, n_ent, n_rel
 
 
 def build(device, rank, world, seed=42):
@@ -49,18 +65,20 @@ def build(device, rank, world, seed=42):
     train_np, n_ent, n_rel = load_fb15k237()
     ents, rels = {i: i for i in range(n_ent)}, {i: i for i in range(n_rel)}
     torch.manual_seed(seed)
-    model = models.RotatE(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA).to(device)
+    model = getattr(models, MODEL)(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA).to(device)
     sampler = sampling.NegativeSampling(size=K, train_triples=train_np, entities=ents, relations=rels, seed=seed)
     # dense-Adam semantics, evaluated row-lazily (bit-identical to the dense kernel, tests/test_gpu_general.py);
     # MKB_BENCH_DENSE_ADAM=1 selects the plain dense streaming kernel instead
     lazy = os.environ.get("MKB_BENCH_DENSE_ADAM", "0") != "1"
-    opt = optim.Adam([p for p in model.parameters() if p.requires_grad and p is not model.modulus], lr=LR, lazy_rows=lazy)
+    opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
+                     lr=LR, lazy_rows=lazy)
     step = FusedTrainStep(model, ALPHA)
     train = torch.as_tensor(train_np, device=device)
     weights = subsampling_weights(train_np).to(device)
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(len(train_np), generator=g).to(device)
-    return dict(model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,
+    train, weights = train[perm].contiguous(), weights[perm].contiguous()  # shuffled once (per epoch in a real loop):
+    return dict(model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,  # batches are views
                 world=world, n_train=len(train_np), exchange=None)
 
 
@@ -68,9 +86,8 @@ def run_step(ctx, i):
     """One training step for this rank's rows of global batch i."""
     n, world, rank = ctx["n_train"], ctx["world"], ctx["rank"]
     lo = ((i * world + rank) * B) % (n - B)
-    idx = ctx["perm"][lo: lo + B]
-    sample = ctx["train"][idx]
-    weight = ctx["weights"][idx]
+    sample = ctx["train"][lo: lo + B]
+    weight = ctx["weights"][lo: lo + B]
     mode = "head-batch" if i % 2 == 0 else "tail-batch"
     ex = ctx["exchange"]
     wsum = ex.weight_sum(weight) if ex is not None else None   # global-batch normaliser (all-reduced scalar)
@@ -158,9 +175,14 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=128)
     ap.add_argument("--profile-kernel", default="auto", help="kernel class bracketed with HIP events (or 'none')")
     ap.add_argument("--breakdown", action="store_true", help="also print per-phase timings (stderr)")
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (default: the headline; the others are for profiles/)")
     ap.add_argument("--mrr-epochs", type=int, default=10,
                     help="after the timed region (N=1 only): train this many more epochs, then filtered MRR on the test set")
     args = ap.parse_args()
+    globals().update(CONFIGS[args.config])
+    if args.config != "headline":
+        args.mrr_epochs, args.no_cpu_baseline = 0, True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -237,7 +259,8 @@ def main():
         return
     triples_per_step = world * B * (K + 1)
     value = triples_per_step * args.steps / dt
-    De, Dr, N, R = 2 * HIDDEN, HIDDEN, 14541, 237
+    m_ = ctx["model"]
+    De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation
     roof = None
     if launches:
         avg_s = kms / launches / 1e3
@@ -264,13 +287,15 @@ def main():
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg, "note": what}
     out = {
-        "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000", "value": value, "unit": "triples/s",
+        "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
+        else f"scored triples/sec (pos+K neg), {args.config}", "value": value, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "FB15k-237 train triples (packaged asset), random-init tables (torch.manual_seed(42)), synthetic batch order",
-        "config": {"workload": "BASELINE configs[2]: datasets.Fb15k237 + models.RotatE hidden_dim=1000, K=256, batch 1024/GPU, "
-                               "Adversarial alpha=1, gamma=9, dense Adam lr=5e-5 (row-lazy exact evaluation); step = sampler + "
-                               "pos/neg forward + loss + backward + Adam",
+        "config": {"workload": ("BASELINE configs[2]: " if args.config == "headline" else f"{args.config}: ")
+                               + f"datasets.{DATASET} + models.{MODEL} hidden_dim={HIDDEN}, K={K}, batch {B}/GPU, "
+                               f"Adversarial alpha={ALPHA}, gamma={GAMMA}, dense Adam lr={LR} (row-lazy exact evaluation); "
+                               "step = sampler + pos/neg forward + loss + backward + Adam",
                    "global_batch": world * B, "negatives": K, "parallelism": f"dp{world}" if world > 1 else "single"},
         "loss": float(loss.item()),
         "roofline": roof,

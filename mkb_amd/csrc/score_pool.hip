@@ -195,22 +195,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     }
 }
 
-// g_ent[pool[p]] += sum over slices of dX[slice][p]   (pool positions may repeat an entity: atomics)
-__global__ __launch_bounds__(256) void pool_scatter_kernel(const float *__restrict__ dX, int nslices, int P,
-                                                           const int64_t *__restrict__ pool, float *__restrict__ g_ent,
-                                                           int64_t De) {
-    const int64_t p = blockIdx.x;
-    float *dst = g_ent + pool[p] * De;
-    for (int64_t k = threadIdx.x; k < De; k += 256) {
-        float v = 0.f;
-        for (int sl = 0; sl < nslices; ++sl) v += dX[((int64_t)sl * P + p) * De + k];
-        if (v != 0.f) atomicAdd(dst + k, v);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 struct Workspace {
-    float *Q, *dQ, *G, *dX, *dpos, *scratch;
+    float *Q, *dQ, *G, *dpos, *scratch;
     size_t bytes;
 };
 
@@ -252,7 +239,6 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.Q = take((size_t)B * De * 4);
     w.dQ = take((size_t)L.q_slices * B * De * 4);
     w.G = take((size_t)B * P * 4);
-    w.dX = take((size_t)L.x_slices * P * De * 4);
     w.dpos = take((size_t)B * 4);
     w.scratch = take((size_t)(B + 1) * 4);
     w.bytes = off;
@@ -262,7 +248,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
 static PoolArgs make_args(const mkb_tables_t *tb, const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t P,
                           const Workspace &w, const PoolLaunch &L) {
     PoolArgs A{};
-    A.ent = tb->ent; A.Q = w.Q; A.pool = pool; A.cnt = cnt; A.G = w.G; A.dQ = w.dQ; A.dX = w.dX;
+    A.ent = tb->ent; A.Q = w.Q; A.pool = pool; A.cnt = cnt; A.G = w.G; A.dQ = w.dQ;
     A.B = (int)B; A.P = (int)P; A.d = tb->hidden_dim; A.De = tb->entity_dim; A.kd = tb->phase_div;
     A.modulus = tb->modulus; A.x_slices = L.x_slices;
     const bool g = tb->model == MKB_TRANSE || tb->model == MKB_ROTATE || tb->model == MKB_PROTATE;
@@ -354,6 +340,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
                       bool chain_queries = true) {
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
     A.g_modulus = gr->g_modulus;
+    A.g_ent = gr->g_ent;
     {
         ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
         if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;
@@ -367,9 +354,6 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
                    (int)B, L.q_slices, tb->phase_div};
         if (int rc = dispatch_query_bwd(tb, head, ra, B, st)) return rc;
     }
-    hipLaunchKernelGGL(pool_scatter_kernel, dim3((unsigned)P), dim3(256), 0, st, w.dX, L.x_slices, (int)P, pool, gr->g_ent,
-                       tb->entity_dim);
-    MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
 

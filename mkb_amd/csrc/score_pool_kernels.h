@@ -18,9 +18,9 @@
 //   pool_bwd_q  same tiling; dq[8][KPT] accumulates in registers over the slice's positions and is stored
 //               once (one partial buffer per slice).  No cross-lane traffic at all.
 //   pool_bwd_x  transposed tiling: workgroup = (tile of 8 pool positions, slice of the batch rows);
-//               x[8][KPT], dx[8][KPT] in registers, walks the rows that use the tile; dx stored once
-//               (one partial buffer per row slice).  The pair term is recomputed instead of exchanging
-//               [B,P,D] products through memory or atomics: VALU is cheaper than either here.
+//               x[8][KPT], dx[8][KPT] in registers, walks the rows that use the tile; dx is added to the table
+//               gradient row once per workgroup (8 atomics per element and step).  The pair term is recomputed
+//               instead of exchanging [B,P,D] products through memory or per-pair atomics: VALU is cheaper.
 // KPT = 2 / 4 lanes load float2 / float4 and give the compiler pairs of units to pack into v_pk_* ops.
 // VALU-bound by design (RotatE: one v_sqrt / v_rsq per (row, slot, complex dim)).
 #pragma once
@@ -43,7 +43,7 @@ struct PoolArgs {
     const float *G;        // [B, P] d loss / d score (backward)
     float *S;              // [B, P] scores (forward)
     float *dQ;             // [slices, B, De] (backward, q pass)
-    float *dX;             // [slices, P, De] (backward, x pass)
+    float *g_ent;          // [N, De] table gradient (backward, x pass adds into it)
     float *g_modulus;      // pRotatE
     const float *modulus;  // pRotatE
     int B, P, d, x_slices;
@@ -510,14 +510,22 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
             }
         }
     }
-    float *dXs = A.dX + (int64_t)sl * A.P * A.De;
+    // dx of this (position tile, row slice) goes straight into the table gradient: x_slices (8) fp32 atomics per
+    // element of a used pool row (~5 M per step, spread over the kernel), instead of a [slices, P, De] partial buffer
+    // plus a reduction kernel.  Tiles nobody uses (n_rows == 0) write nothing.
+    if (n_rows > 0) {
 #pragma unroll
-    for (int t = 0; t < TI; ++t) {
-        if constexpr (CP && KPT % 2 == 0) {
+        for (int t = 0; t < TI; ++t) {
+            if (p0 + t < A.P && u0 < NU) {
+                float *row = A.g_ent + A.pool[p0 + t] * A.De;
+                const float sgn = (CP && KPT % 2 == 0) ? -1.f : 1.f;  // the packed path accumulated -dx
 #pragma unroll
-            for (int v = 0; v < KPT; ++v) { dx0[t][v] = -dx0[t][v]; dx1[t][v] = -dx1[t][v]; }
+                for (int v = 0; v < KPT; ++v) {
+                    atomicAdd(row + u0 + v, sgn * dx0[t][v]);
+                    if constexpr (CP) atomicAdd(row + A.d + u0 + v, sgn * dx1[t][v]);
+                }
+            }
         }
-        if (p0 + t < A.P) store_units<CP, KPT>(dXs + (int64_t)(p0 + t) * A.De, A.d, NU, u0, dx0[t], dx1[t]);
     }
 }
 

@@ -42,8 +42,11 @@ class DeviceBatches:
         return torch.arange(n, device=self.device)
 
     def __iter__(self):
-        head, tail = self._order(), self._order()
+        views = []
+        for mode in ("head-batch", "tail-batch"):  # one gather per view and epoch; the batches are slices of it
+            order = self._order()
+            views.append((self.triples[order], self.weights[order], mode))
         for lo in range(0, len(self.triples), self.batch_size):
-            for order, mode in ((head, "head-batch"), (tail, "tail-batch")):
-                idx = order[lo: lo + self.batch_size]
-                yield {"sample": self.triples[idx], "weight": self.weights[idx], "mode": mode}
+            for triples, weights, mode in views:
+                yield {"sample": triples[lo: lo + self.batch_size], "weight": weights[lo: lo + self.batch_size],
+                       "mode": mode}

@@ -61,6 +61,7 @@ class Adam:
         if upto <= 0:
             return
         ids = _hip.contiguous(ids, torch.int64)
+        st["caught_up"] = (ids, upto)
         with torch.cuda.device(p.device):
             _hip.check(_hip.lib().mkb_adam_rows_catchup(_hip.ptr(p.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
                                                         _hip.ptr(st["last"]), _hip.ptr(self._consts(st, upto)), p.shape[0],
@@ -102,7 +103,9 @@ class Adam:
                     st["n"] += 1
                     ids = _hip.contiguous(touched, torch.int64)
                     c = self._consts(st, st["n"])
-                    self.catch_up(p, ids, upto=st["n"] - 1)  # rows touched by OTHER data-parallel ranks only
+                    done = st.get("caught_up")
+                    if done is None or done[0] is not touched or done[1] != st["n"] - 1:
+                        self.catch_up(p, ids, upto=st["n"] - 1)  # e.g. rows only OTHER data-parallel ranks touched
                     _hip.check(lib.mkb_adam_rows_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
                                                       _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1],
                                                       _hip.ptr(ids), ids.numel(), st["n"], self.lr, self.betas[0],
