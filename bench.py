@@ -190,13 +190,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MKB_BENCH_ONE_DEVICE=1: functional check of the N>1 path on a single-GPU box (all ranks on cuda:0, gloo)
+    one_dev = os.environ.get("MKB_BENCH_ONE_DEVICE", "0") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     from mkb_amd import _hip
 
     ctx = build(device, rank, world)
@@ -247,6 +253,12 @@ def main():
         dt = t.item()
     ctx["sampler"].check()
     assert torch.isfinite(loss).item()
+    if world > 1:  # replicas must hold identical tables after identical updates
+        probe = ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1)
+        lo_, hi_ = probe.clone(), probe.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        assert lo_.item() == hi_.item(), "data-parallel replicas diverged"
 
     launches, kms = (0, 0.0)
     if prof_kind != "none":
