@@ -11,10 +11,12 @@ alpha=1, gamma=9, Adam lr 5e-5.  One step = what compose/pipeline.py:206-240 doe
 and scores B*(K+1) = 263,168 triples per GPU.  Inputs (training triples, subsampling weights, tables, optimizer
 state) are resident in HBM before the timed region; batches are index-selected on the device.
 
-Multi-GPU (N > 1): batch-row data parallel, weak scaling -- every rank scores its own 1024 rows of a global
-batch of N*1024 against the SAME candidate pool (replicated MT19937 state), tables replicated; per step the
-ranks exchange only the touched gradient rows over RCCL (mkb_amd.parallel) and apply the identical dense Adam
-step to their replica.
+Multi-GPU (N > 1), weak scaling with a global batch of N*1024 rows scored against ONE candidate pool (replicated
+MT19937 state).  Default --parallelism dims: the embedding DIMENSION is sharded (rank g holds 1/N of every table
+column-wise, 1/N of the optimizer state); every rank scores all N*1024 rows on its dims, ONE RCCL all-reduce of the
+partial scores [N*1024, 2K+1] per step, then loss / backward / Adam are local -- no gradient exchange.
+--parallelism rows: batch-row data parallel with replicated tables and a sparse all-reduce of the touched gradient
+rows (mkb_amd.parallel.SparseGradExchange).
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kernel (HIP-event timed inside the
 timed region) and "cpu_baseline" (the oracle restatement of the reference's PyTorch-CPU path on a bounded sample).
@@ -57,38 +59,49 @@ def load_fb15k237():
     return tr, n_ent, n_rel
 
 
-def build(device, rank, world, seed=42):
-    from mkb_amd import models, optim, sampling
+def build(device, rank, world, seed=42, parallelism="dims"):
+    from mkb_amd import models, optim, parallel, sampling
     from mkb_amd.datasets.base import subsampling_weights
     from mkb_amd.fused import FusedTrainStep
 
     train_np, n_ent, n_rel = load_fb15k237()
     ents, rels = {i: i for i in range(n_ent)}, {i: i for i in range(n_rel)}
     torch.manual_seed(seed)
-    model = getattr(models, MODEL)(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA).to(device)
+    model = getattr(models, MODEL)(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA)
+    dims = world > 1 and parallelism == "dims"
+    model = parallel.shard_dims(model, rank, world, device) if dims else model.to(device)
     sampler = sampling.NegativeSampling(size=K, train_triples=train_np, entities=ents, relations=rels, seed=seed)
     # dense-Adam semantics, evaluated row-lazily (bit-identical to the dense kernel, tests/test_gpu_general.py);
     # MKB_BENCH_DENSE_ADAM=1 selects the plain dense streaming kernel instead
     lazy = os.environ.get("MKB_BENCH_DENSE_ADAM", "0") != "1"
     opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
                      lr=LR, lazy_rows=lazy)
-    step = FusedTrainStep(model, ALPHA)
+    step = parallel.DimShardedStep(model, ALPHA) if dims else FusedTrainStep(model, ALPHA)
     train = torch.as_tensor(train_np, device=device)
     weights = subsampling_weights(train_np).to(device)
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(len(train_np), generator=g).to(device)
     train, weights = train[perm].contiguous(), weights[perm].contiguous()  # shuffled once (per epoch in a real loop):
     return dict(model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,  # batches are views
-                world=world, n_train=len(train_np), exchange=None)
+                world=world, n_train=len(train_np), exchange=None, dims=dims)
 
 
 def run_step(ctx, i):
     """One training step for this rank's rows of global batch i."""
     n, world, rank = ctx["n_train"], ctx["world"], ctx["rank"]
+    mode = "head-batch" if i % 2 == 0 else "tail-batch"
+    if ctx["dims"]:  # dimension sharding: every rank scores ALL world*B rows of the global batch on its 1/world of the dims
+        gb = world * B
+        lo = (i * gb) % (n - gb)
+        sample, weight = ctx["train"][lo: lo + gb], ctx["weights"][lo: lo + gb]
+        neg = ctx["sampler"].generate(sample, mode)
+        loss = ctx["step"](sample, weight, neg, mode)  # one all-reduce of the partial scores inside
+        ctx["opt"].step()
+        ctx["opt"].zero_grad()
+        return loss
     lo = ((i * world + rank) * B) % (n - B)
     sample = ctx["train"][lo: lo + B]
     weight = ctx["weights"][lo: lo + B]
-    mode = "head-batch" if i % 2 == 0 else "tail-batch"
     ex = ctx["exchange"]
     wsum = ex.weight_sum(weight) if ex is not None else None   # global-batch normaliser (all-reduced scalar)
     neg = ctx["sampler"].generate(sample, mode)
@@ -175,6 +188,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=128)
     ap.add_argument("--profile-kernel", default="auto", help="kernel class bracketed with HIP events (or 'none')")
     ap.add_argument("--breakdown", action="store_true", help="also print per-phase timings (stderr)")
+    ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "dims"), choices=["dims", "rows"],
+                    help="N>1: 'dims' = shard the embedding dimension (one all-reduce of partial scores per step, no "
+                         "gradient exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce")
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (default: the headline; the others are for profiles/)")
     ap.add_argument("--mrr-epochs", type=int, default=10,
@@ -205,8 +221,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     from mkb_amd import _hip
 
-    ctx = build(device, rank, world)
-    if world > 1:
+    ctx = build(device, rank, world, parallelism=args.parallelism)
+    if world > 1 and not ctx["dims"]:
         from mkb_amd import parallel
 
         ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], equal_batches=True)
@@ -253,8 +269,9 @@ def main():
         dt = t.item()
     ctx["sampler"].check()
     assert torch.isfinite(loss).item()
-    if world > 1:  # replicas must hold identical tables after identical updates
-        probe = ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1)
+    if world > 1:  # rows: replicas must hold identical tables; dims: every rank must have computed the same loss
+        probe = (loss.detach().double().reshape(1) if ctx["dims"]
+                 else ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1))
         lo_, hi_ = probe.clone(), probe.clone()
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
@@ -272,7 +289,8 @@ def main():
     triples_per_step = world * B * (K + 1)
     value = triples_per_step * args.steps / dt
     m_ = ctx["model"]
-    De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation
+    De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation  # per rank (dims: 1/world of the row)
+    Bk = world * B if ctx["dims"] else B                                        # rows each rank's kernels see
     roof = None
     if launches:
         avg_s = kms / launches / 1e3
@@ -284,7 +302,7 @@ def main():
         else:
             # logical gather/scatter bytes of the reference formulation, per pass over the negatives:
             # every scored slot reads its entity row (fwd) / re-reads it and adds one gradient row (bwd)
-            alg = B * K * De * 4
+            alg = Bk * K * De * 4
             what = (f"{prof_kind} kernel: logical bytes of the reference formulation (B*K entity rows of {De * 4} B "
                     f"gathered / re-read / scattered once by this pass); the kernel itself is VALU-bound and reuses "
                     f"each pool row from registers, so the logical rate may exceed the HBM peak")
@@ -308,7 +326,9 @@ def main():
                                + f"datasets.{DATASET} + models.{MODEL} hidden_dim={HIDDEN}, K={K}, batch {B}/GPU, "
                                f"Adversarial alpha={ALPHA}, gamma={GAMMA}, dense Adam lr={LR} (row-lazy exact evaluation); "
                                "step = sampler + pos/neg forward + loss + backward + Adam",
-                   "global_batch": world * B, "negatives": K, "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "global_batch": world * B, "negatives": K, "parallelism": (f"dims{world} (embedding dimension sharded, 1 score all-reduce/step)"
+                                                                if ctx["dims"] else f"dp{world} (rows, sparse grad all-reduce)")
+                   if world > 1 else "single"},
         "loss": float(loss.item()),
         "roofline": roof,
     }

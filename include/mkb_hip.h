@@ -127,6 +127,16 @@ int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t
 int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                   const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
                   const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
+/* The two halves of mkb_pool_step (mkb_pool_step == fwd then bwd on the same buffers).  A caller that shards the
+ * embedding DIMENSIONS over devices sums pos_score / pool_score across devices between the halves (scores are sums
+ * over dims) and adds gamma once; each device then back-propagates into its own slice with no further exchange. */
+int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt, int64_t B,
+                      int64_t K, int mode, float *pos_score, float *pool_score, void *ws, void *stream);
+int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                      const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                      const float *weight_sum, const float *pos_score, const float *pool_score, float *loss, void *ws,
+                      void *stream);
+
 /* pooled model.forward / its autograd as separate calls (README-style loops that call the model and the loss
  * themselves): pool_score [B,2K] out; dpool_score [B,2K] = d loss / d pool_score in. */
 int mkb_pool_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,

@@ -62,6 +62,10 @@ _SIGNATURES = {
     "mkb_pool_step_workspace_bytes": (c_int64, [POINTER(Tables), c_int64, c_int64]),
     "mkb_pool_step": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                               c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mkb_pool_step_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "mkb_pool_step_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                  c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_pool_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p]),
     "mkb_pool_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,

@@ -214,20 +214,23 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const bool al16 = (((uintptr_t)tb->ent) & 15) == 0;
     const bool even2 = al16 && NU % 2 == 0 && De % 2 == 0 && (!cp || d % 2 == 0);
     const bool even4 = al16 && NU % 4 == 0 && De % 4 == 0 && (!cp || d % 4 == 0);
-    if (NU <= 256) { L.kpt = 1; L.nw = 4; }
-    else if (NU <= 1024 && even2) { L.kpt = 2; L.nw = 8; }
-    else if (NU <= 1024) { L.kpt = 1; L.nw = 16; }
-    else if (NU <= 2048 && even2) { L.kpt = 2; L.nw = 16; }
-    else if (NU <= 4096 && even4) { L.kpt = 4; L.nw = 16; }
+    // units per lane: vector loads + packed math need even dims; waves: smallest workgroup that covers the row
+    if (even2 && NU >= 128 && NU <= 2048) L.kpt = 2;
+    else if (even4 && NU > 2048 && NU <= 4096) L.kpt = 4;
+    else if (NU <= 1024) L.kpt = 1;
     else return false;
+    const int lanes = (NU + L.kpt - 1) / L.kpt;
+    if (L.kpt == 1) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : 16);
+    else if (L.kpt == 2) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : (lanes <= 512 ? 8 : 16));
+    else L.nw = 16;
     const int target = 256 * 16 / L.nw;  // workgroups for ~16 waves per CU
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     L.fwd_slices = clampi((target + row_tiles - 1) / row_tiles, 1, kMaxSlices);
     L.q_slices = L.fwd_slices;
-    const int min_x = (int)((B + 1023) / 1024);
+    // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
+    const int min_x = (int)((B + 255) / 256);
     L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
-    if (L.x_slices > 16 && L.x_slices > min_x) L.x_slices = min_x > 16 ? min_x : 16;
     return true;
 }
 
@@ -412,10 +415,34 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
     return pooled_bwd(tb, mode_is_head(mode), gr, sample, pool, cnt, B, 2 * K, w, L, st);
 }
 
-extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
-                             const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
-                             const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws,
-                             void *stream) {
+// The two halves of mkb_pool_step.  Between them the caller may combine the scores of several devices that each
+// hold a slice of the embedding DIMENSIONS (mkb_amd.parallel.DimSharded*): scores are sums over dims, so the halves'
+// only coupling is pos_score / pool_score.
+extern "C" int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
+                                 int64_t B, int64_t K, int mode, float *pos_score, float *pool_score, void *ws,
+                                 void *stream) {
+    PoolLaunch L;
+    if (int rc = check_pool_call(tb, sample, pool, cnt, B, K, mode, ws, L)) return rc;
+    MKB_REQUIRE(pos_score && pool_score, "null pointer");
+    const int64_t P = 2 * K;
+    const Workspace w = carve(ws, B, P, tb->entity_dim, L);
+    hipStream_t st = (hipStream_t)stream;
+    const bool head = mode_is_head(mode);
+    RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, pos_score, w.dpos, nullptr, nullptr, nullptr,
+                   tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
+    // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
+    {
+        ProfScope ps(MKB_PROF_GENERAL_FWD, st);
+        if (int rc = dispatch_row_fwd(tb, head, ra, B, st)) return rc;
+    }
+    // negative pass over the shared pool (pipeline.py:230-232)
+    return pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false);
+}
+
+extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                                 const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                                 const float *weight_sum, const float *pos_score, const float *pool_score, float *loss,
+                                 void *ws, void *stream) {
     PoolLaunch L;
     if (int rc = check_pool_call(tb, sample, pool, cnt, B, K, mode, ws, L)) return rc;
     MKB_REQUIRE(gr && gr->g_ent && gr->g_rel && weight && pos_score && pool_score && loss, "null pointer");
@@ -424,19 +451,21 @@ extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, cons
     const Workspace w = carve(ws, B, P, tb->entity_dim, L);
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode_is_head(mode);
-    RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, pos_score, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
+    RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, nullptr, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
-    // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
-    {
-        ProfScope ps(MKB_PROF_GENERAL_FWD, st);
-        if (int rc = dispatch_row_fwd(tb, head, ra, B, st)) return rc;
-    }
-    // negative pass over the shared pool (pipeline.py:230-232)
-    if (int rc = pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false)) return rc;
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
     if (int rc = mkb_adversarial(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, stream)) return rc;
     // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false)) return rc;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     return dispatch_row_bwd(tb, head, ra, B, st);
+}
+
+extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                             const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                             const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws,
+                             void *stream) {
+    if (int rc = mkb_pool_step_fwd(tb, sample, pool, cnt, B, K, mode, pos_score, pool_score, ws, stream)) return rc;
+    return mkb_pool_step_bwd(tb, gr, sample, weight, pool, cnt, B, K, mode, alpha, weight_sum, pos_score, pool_score, loss, ws,
+                             stream);
 }

@@ -144,9 +144,10 @@ template <int MODEL, bool HEAD, int KPT, int NW>
 __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    __shared__ int s_row[kMaxP];                // entity id per active position
-    __shared__ int s_pos[kMaxP];                // pool position
-    __shared__ unsigned s_mask[kMaxP];          // bit r: row r of the tile uses it
+    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // sized by the launch: 3 * P words
+    int *s_row = lds_dyn;                                           // entity id per active position
+    int *s_pos = lds_dyn + A.P;                                     // pool position
+    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + 2 * A.P);  // bit r: row r of the tile uses it
     __shared__ float s_part[2][kSlab][NW][TI];  // wave totals, double buffered
     __shared__ int s_wave_cnt[NW];
 
@@ -266,11 +267,14 @@ template <int MODEL, bool HEAD, int KPT, int NW>
 __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    __shared__ int s_row[kMaxP];
-    __shared__ unsigned s_mask[kMaxP];
-    __shared__ __attribute__((aligned(16))) float s_g[kMaxP][TI];  // gradient seeds of the tile per active position
-    __shared__ int s_wave_cnt[NW];
-    __shared__ float s_red[NW];
+    // ALL LDS is dynamic (10 * P + 32 words): a static __shared__ in front of the dynamic region can shift its base
+    // off 16 bytes, and the ds_read_b128 of s_g would then be replayed (cdna guide, G17)
+    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];
+    float (*s_g)[TI] = reinterpret_cast<float (*)[TI]>(lds_dyn);   // [P][8] gradient seeds of the tile per active position
+    int *s_row = lds_dyn + TI * A.P;
+    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * A.P);
+    int *s_wave_cnt = lds_dyn + (TI + 2) * A.P;
+    float *s_red = reinterpret_cast<float *>(lds_dyn + (TI + 2) * A.P + 16);
 
     const int tid = threadIdx.x;
     const int i0 = blockIdx.x * TI;
@@ -398,11 +402,7 @@ template <int MODEL, bool HEAD, int KPT, int NW>
 __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    constexpr int kMaxRows = 1024;       // rows per slice (host picks the slice count accordingly)
-    __shared__ int s_i[kMaxRows];        // batch rows of the slice that use the position tile
-    __shared__ unsigned s_mask[kMaxRows];// bit t: the row uses position p0 + t
-    __shared__ __attribute__((aligned(16))) float s_g[kMaxRows][TI];
-    __shared__ int s_wave_cnt[NW];
+    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // all LDS dynamic: 10 * rows_per + 16 words
 
     const int tid = threadIdx.x;
     // 1-D grid, tile-major: the workgroups of the low position tiles (used by every row: the heavy ones) are
@@ -411,8 +411,12 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
     const int p0 = (blockIdx.x / nsl) * TI;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
-    const int rows_per = (A.B + nsl - 1) / nsl;  // <= kMaxRows
+    const int rows_per = (A.B + nsl - 1) / nsl;
     const int r_lo = sl * rows_per, r_hi = min(A.B, r_lo + rows_per);
+    float (*s_g)[TI] = reinterpret_cast<float (*)[TI]>(lds_dyn);          // [rows_per][8]
+    int *s_i = lds_dyn + TI * rows_per;                                   // batch rows of the slice that use the tile
+    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * rows_per);  // bit t: row uses position p0 + t
+    int *s_wave_cnt = lds_dyn + (TI + 2) * rows_per;
 
     int n_rows = 0;
     for (int base = r_lo; base < r_hi; base += WG) {
@@ -549,13 +553,14 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
     const dim3 block(NW * 64);
     if (which == 0) {
         dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.fwd_slices);
-        hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+        hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, (size_t)3 * A.P * 4, st, A);
     } else if (which == 1) {
         dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.q_slices);
-        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((size_t)(TI + 2) * A.P + 32) * 4, st, A);
     } else {
         dim3 grid((unsigned)(((A.P + TI - 1) / TI) * L.x_slices));
-        hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, KPT, NW>), grid, block, 0, st, A);
+        const size_t rows_per = (size_t)((A.B + L.x_slices - 1) / L.x_slices);
+        hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((TI + 2) * rows_per + 16) * 4, st, A);
     }
     MKB_LAUNCH_CHECK();
     return MKB_OK;
@@ -563,8 +568,11 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
 
 template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+    if (L.kpt == 1 && L.nw == 2) return launch_cfg<MODEL, HEAD, 1, 2>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 4) return launch_cfg<MODEL, HEAD, 1, 4>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 16) return launch_cfg<MODEL, HEAD, 1, 16>(which, L, A, st);
+    if (L.kpt == 2 && L.nw == 2) return launch_cfg<MODEL, HEAD, 2, 2>(which, L, A, st);
+    if (L.kpt == 2 && L.nw == 4) return launch_cfg<MODEL, HEAD, 2, 4>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 8) return launch_cfg<MODEL, HEAD, 2, 8>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 16) return launch_cfg<MODEL, HEAD, 2, 16>(which, L, A, st);
     if (L.kpt == 4 && L.nw == 16) return launch_cfg<MODEL, HEAD, 4, 16>(which, L, A, st);

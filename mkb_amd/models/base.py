@@ -111,6 +111,9 @@ class BaseModel(Base):
     def _constants(self):
         """(gamma, phase_div) as python floats; read once (each .item() is a device sync) and refreshed when
         the parameters are replaced (``_set_params``, ``.to()``, ``load_state_dict``)."""
+        override = getattr(self, "_consts_override", None)
+        if override is not None:  # dimension shard of a larger model (mkb_amd.parallel.shard_dims)
+            return override
         if self._consts is None:
             gamma = self.gamma.item()
             phase_div = torch.tensor(self.embedding_range.item() / math.pi, dtype=torch.float32).item()

@@ -23,7 +23,7 @@ backend in tests/test_parallel_gloo.py.
 import torch
 import torch.distributed as dist
 
-__all__ = ["SparseGradExchange", "allreduce_touched_rows", "shard_rows"]
+__all__ = ["DimShardedStep", "SparseGradExchange", "allreduce_touched_rows", "gather_dims", "shard_dims", "shard_rows"]
 
 
 def shard_rows(n_rows, rank, world):
@@ -122,3 +122,126 @@ class SparseGradExchange:
         if self.world > 1:
             dist.all_reduce(t, group=self.group)
         return t.reshape(())
+
+
+# =====================================================================================================
+# Dimension sharding ("tensor parallel" over the embedding dimension)
+#
+# Every score of the five models is a SUM OVER EMBEDDING DIMS of terms that couple only same-index components of
+# h, r, t (complex models: the same complex index).  So the tables can be split by COLUMNS: rank g keeps
+# ent[:, dims_g] / rel[:, dims_g] (1/G of the memory), scores every row of the global batch on its dims, and the
+# only exchange per step is ONE all-reduce of the partial scores [B, 2K+1] (2 MB at B = 1024) -- after which loss,
+# backward and Adam are entirely local to the rank's columns: no gradient exchange at all, no replicated optimizer
+# work, table and optimizer state sharded G ways.  Compare with row/batch sharding, where the ranks must exchange
+# the touched gradient ROWS (tens of MB per step, see SparseGradExchange above).
+# Weak scaling: the global batch grows with G (G x 1024 rows), each rank does all rows x 1/G of the dims.
+
+
+def _dim_slices(model, rank, world):
+    """(entity column index, relation column index) of this rank's dims, matching the [real | imag] row layout."""
+    d = model.hidden_dim
+    if d % world:
+        raise ValueError(f"hidden_dim {d} is not divisible by world size {world}")
+    dl = d // world
+    own = torch.arange(rank * dl, (rank + 1) * dl)
+    if model.name == "RotatE":
+        return torch.cat([own, d + own]), own
+    if model.name == "ComplEx":
+        return torch.cat([own, d + own]), torch.cat([own, d + own])
+    return own, own
+
+
+def shard_dims(model, rank, world, device=None):
+    """A model of the same class holding this rank's 1/world of the embedding dims of ``model`` (a full model,
+    e.g. freshly initialised with the reference's seed on the CPU).  Its forward returns PARTIAL scores (gamma is
+    added once after the all-reduce, by DimShardedStep)."""
+    import math
+
+    ec, rc = _dim_slices(model, rank, world)
+    local = model.__class__(hidden_dim=model.hidden_dim // world, entities={v: k for k, v in model.entities.items()},
+                            relations={v: k for k, v in model.relations.items()}, gamma=model.gamma.item())
+    with torch.no_grad():
+        local.entity_embedding.copy_(model.entity_embedding.detach().cpu()[:, ec])
+        local.relation_embedding.copy_(model.relation_embedding.detach().cpu()[:, rc])
+        local.embedding_range.copy_(model.embedding_range.detach().cpu())
+        if hasattr(model, "modulus"):
+            local.modulus.copy_(model.modulus.detach().cpu())
+    phase_div = torch.tensor(model.embedding_range.item() / math.pi, dtype=torch.float32).item()
+    local._consts_override = (0.0, phase_div)  # partial scores: gamma is added after the cross-rank sum
+    local._dim_shard = (rank, world, model.gamma.item(), model.name in ("TransE", "RotatE", "pRotatE"))
+    return local if device is None else local.to(device)
+
+
+def gather_dims(local, group=None):
+    """Reassemble the full tables from every rank's dimension shard: (entity_embedding, relation_embedding)."""
+    rank, world, _, _ = local._dim_shard
+    opt = getattr(local.entity_embedding, "_mkb_lazy", None)
+    if opt is not None:
+        opt.flush(local.entity_embedding)
+    outs = []
+    for p, complex_rows in ((local.entity_embedding, local.name in ("RotatE", "ComplEx")),
+                            (local.relation_embedding, local.name == "ComplEx")):
+        parts = [torch.empty_like(p.data) for _ in range(world)]
+        dist.all_gather(parts, p.data.contiguous(), group=group)
+        if complex_rows:
+            h = p.shape[1] // 2
+            outs.append(torch.cat([q[:, :h] for q in parts] + [q[:, h:] for q in parts], dim=1))
+        else:
+            outs.append(torch.cat(parts, dim=1))
+    return outs[0], outs[1]
+
+
+class DimShardedStep:
+    """The fused training step (mkb_amd.fused.FusedTrainStep) over a dimension-sharded model: forward half on the
+    local dims, ONE all-reduce of the partial scores, backward half on the local dims.  Every rank must be given
+    the same (global) batch and draw the same negatives (same sampler seed)."""
+
+    def __init__(self, local_model, alpha, group=None):
+        from . import _hip
+        from .fused import _workspace
+
+        self._hip, self._workspace = _hip, _workspace
+        self.model, self.alpha, self.group = local_model, float(alpha), group
+        self.rank, self.world, self.gamma, self.uses_gamma = local_model._dim_shard
+
+    def __call__(self, sample, weight, negative_sample, mode):
+        _hip, m = self._hip, self.model
+        info = negative_sample._mkb_pool
+        mode_id = _hip.mode_id(mode)
+        sample = _hip.contiguous(sample, torch.int64)
+        weight = _hip.contiguous(weight, torch.float32)
+        B, K = sample.shape[0], info.size
+        dev = sample.device
+        scores = torch.empty(B * (2 * K + 1), dtype=torch.float32, device=dev)  # [pos | pool]: one all-reduce
+        pos, S = scores[:B], scores[B:].view(B, 2 * K)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = self._workspace(m, B, K)
+        params = [m.entity_embedding, m.relation_embedding] + ([m.modulus] if m.name == "pRotatE" else [])
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        gr = _hip.Grads(m.entity_embedding.grad.data_ptr(), m.relation_embedding.grad.data_ptr(),
+                        m.modulus.grad.data_ptr() if m.name == "pRotatE" else None)
+        ent = m.entity_embedding
+        lazy = getattr(ent, "_mkb_lazy", None)
+        if lazy is not None:
+            ids = torch.cat([info.pool, sample[:, 0], sample[:, 2]])
+            lazy.catch_up(ent, ids)
+            ent._mkb_touched = ids
+        lib, tb = _hip.lib(), m._tables()
+        with torch.cuda.device(dev):
+            _hip.check(lib.mkb_pool_step_fwd(tb, _hip.ptr(sample), _hip.ptr(info.pool), _hip.ptr(info.cnt), B, K, mode_id,
+                                             _hip.ptr(pos), _hip.ptr(S), _hip.ptr(ws), _hip.stream_ptr()),
+                       "mkb_pool_step_fwd")
+        if self.world > 1:
+            dist.all_reduce(scores, group=self.group)
+        if self.uses_gamma:
+            scores += self.gamma
+        with torch.cuda.device(dev):
+            _hip.check(lib.mkb_pool_step_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
+                                             _hip.ptr(info.cnt), B, K, mode_id, self.alpha, None, _hip.ptr(pos), _hip.ptr(S),
+                                             _hip.ptr(loss), _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_step_bwd")
+        if m.name == "pRotatE" and self.world > 1:
+            dist.all_reduce(m.modulus.grad, group=self.group)  # the modulus is replicated: its gradient sums over dims
+        self.positive_score, self._S, self._info = pos.view(B, 1), S, info
+        return loss.reshape(())

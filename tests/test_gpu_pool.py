@@ -234,3 +234,24 @@ def test_device_ranking_equals_reference_route(name):
     ev.force_reference_path = True
     slow = ev.eval(model=m, dataset=test)
     assert fast == slow, (fast, slow)
+
+
+@pytest.mark.parametrize("name,hidden,world", [("RotatE", 48, 2), ("ComplEx", 32, 4), ("TransE", 500, 2), ("pRotatE", 40, 2),
+                                                ("DistMult", 36, 3)])
+def test_dim_sharded_training_equals_single_device(name, hidden, world):
+    """Embedding-dimension sharding over `world` processes (gloo, all on this GPU): 6 fused steps + lazy Adam leave
+    the same tables and losses as the single-process fused step."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "tp_worker.py"), name, str(hidden), "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
+    assert out.returncode == 0 and "TP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

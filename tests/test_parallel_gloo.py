@@ -105,3 +105,30 @@ def test_shard_rows_partition():
             parts = [shard_rows(n, r, world) for r in range(world)]
             assert parts[0][0] == 0 and parts[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+def test_scores_are_sums_over_dimension_shards():
+    """The identity dimension sharding rests on (oracle closed form, no distributed runtime needed): for every model
+    the score is c0 + sum over shards of the shard's partial sum, with the phase divisor taken from the GLOBAL dims."""
+    from oracle import closed, scoring
+
+    rs = np.random.RandomState(0)
+    N, R, d, B, K, gamma, world = 30, 4, 12, 5, 6, 6.0, 3
+    sample = np.stack([rs.randint(N, size=B), rs.randint(R, size=B), rs.randint(N, size=B)], 1)
+    neg = rs.randint(N, size=(B, K))
+    k = closed.emb_range_over_pi(gamma, d)
+    for model in scoring.MODELS:
+        de, dr = scoring.dims(model, d)
+        ent, rel = rs.randn(N, de) * 0.3, rs.randn(R, dr) * 0.3
+        for mode in ("head-batch", "tail-batch"):
+            head = mode == "head-batch"
+            full = closed.scores(model, ent, rel, sample, neg, mode, gamma, d, modulus=np.array([[0.7]]))
+            total = np.zeros_like(full)
+            for g in range(world):
+                own = np.arange(g * d // world, (g + 1) * d // world)
+                ec = np.concatenate([own, d + own]) if model in ("RotatE", "ComplEx") else own
+                rc = np.concatenate([own, d + own]) if model == "ComplEx" else own
+                q = closed.build_query(model, ent[:, ec], rel[:, rc], sample, head, k)
+                total += closed.pair_scores(model, q, ent[:, ec][neg], head, 0.0, k, 0.7)   # partial: gamma = 0
+            c0 = float(np.float32(gamma)) if model in ("TransE", "RotatE", "pRotatE") else 0.0
+            np.testing.assert_allclose(total + c0, full, rtol=0, atol=1e-12)
