@@ -140,10 +140,9 @@ class SparseGradExchange:
 def _dim_slices(model, rank, world):
     """(entity column index, relation column index) of this rank's dims, matching the [real | imag] row layout."""
     d = model.hidden_dim
-    if d % world:
-        raise ValueError(f"hidden_dim {d} is not divisible by world size {world}")
-    dl = d // world
-    own = torch.arange(rank * dl, (rank + 1) * dl)
+    if d < world:
+        raise ValueError(f"hidden_dim {d} is smaller than the world size {world}")
+    own = torch.tensor_split(torch.arange(d), world)[rank]  # uneven splits allowed (500 dims over 8 ranks: 63 / 62)
     if model.name == "RotatE":
         return torch.cat([own, d + own]), own
     if model.name == "ComplEx":
@@ -158,7 +157,7 @@ def shard_dims(model, rank, world, device=None):
     import math
 
     ec, rc = _dim_slices(model, rank, world)
-    local = model.__class__(hidden_dim=model.hidden_dim // world, entities={v: k for k, v in model.entities.items()},
+    local = model.__class__(hidden_dim=int(rc.numel() // (2 if model.name == "ComplEx" else 1)), entities={v: k for k, v in model.entities.items()},
                             relations={v: k for k, v in model.relations.items()}, gamma=model.gamma.item())
     with torch.no_grad():
         local.entity_embedding.copy_(model.entity_embedding.detach().cpu()[:, ec])
@@ -181,11 +180,18 @@ def gather_dims(local, group=None):
     outs = []
     for p, complex_rows in ((local.entity_embedding, local.name in ("RotatE", "ComplEx")),
                             (local.relation_embedding, local.name == "ComplEx")):
-        parts = [torch.empty_like(p.data) for _ in range(world)]
-        dist.all_gather(parts, p.data.contiguous(), group=group)
+        width = torch.tensor([p.shape[1]], device=p.device)
+        widths = [torch.zeros_like(width) for _ in range(world)]
+        dist.all_gather(widths, width, group=group)
+        widths = [int(w.item()) for w in widths]
+        wmax = max(widths)
+        mine = torch.zeros(p.shape[0], wmax, dtype=p.dtype, device=p.device)
+        mine[:, : p.shape[1]] = p.data
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        parts = [q[:, :w] for q, w in zip(parts, widths)]
         if complex_rows:
-            h = p.shape[1] // 2
-            outs.append(torch.cat([q[:, :h] for q in parts] + [q[:, h:] for q in parts], dim=1))
+            outs.append(torch.cat([q[:, : q.shape[1] // 2] for q in parts] + [q[:, q.shape[1] // 2:] for q in parts], dim=1))
         else:
             outs.append(torch.cat(parts, dim=1))
     return outs[0], outs[1]
