@@ -255,3 +255,73 @@ def test_dim_sharded_training_equals_single_device(name, hidden, world):
            "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "tp_worker.py"), name, str(hidden), "16"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
     assert out.returncode == 0 and "TP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", ["RotatE", "TransE", "ComplEx"])
+@pytest.mark.parametrize("B,K,hidden", [(1, 3, 6), (13, 5, 33), (9, 7, 130)])
+def test_fused_step_edge_shapes_with_wrapping_rows(name, B, K, hidden):
+    """Tiny entity set: the filter removes most of the pool, rows wrap around their survivors (a pool position is
+    used several times by one row: multiplicities > 1), B is not a multiple of the row tile, odd dims (scalar-lane
+    kernels) and even dims (vector-lane kernels)."""
+    from mkb_amd import models, sampling
+    from mkb_amd.fused import FusedTrainStep, pooled_supported
+    from oracle import scoring
+
+    N, R = 6, 2
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(B * 31 + K)
+    train = sorted({(int(rs.randint(N)), int(rs.randint(R)), int(rs.randint(N))) for _ in range(60)})  # dense: big true sets
+    torch.manual_seed(B + K)
+    m = getattr(models, name)(hidden_dim=hidden, entities=ents, relations=rels, gamma=4.0)
+    tb = scoring.Tables(name, hidden, 4.0, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(),
+                        m.modulus.detach().clone() if hasattr(m, "modulus") else None)
+    m = m.cuda()
+    assert pooled_supported(m, B, K)
+    ns = sampling.NegativeSampling(size=K, train_triples=train, entities=ents, relations=rels, seed=11)
+    step = FusedTrainStep(m, alpha=0.5)
+    wrapped = False
+    for it, mode in enumerate(["tail-batch", "head-batch"] * 8):
+        idx = rs.randint(len(train), size=B)
+        s = torch.tensor([train[i] for i in idx]).cuda()
+        w = (torch.rand(B) + 0.1).cuda()
+        try:
+            neg = ns.generate(s, mode)
+            ns.check()
+        except RuntimeError:  # a row's true set covers the whole pool: the reference would hang; skip that batch
+            ns = sampling.NegativeSampling(size=K, train_triples=train, entities=ents, relations=rels, seed=100 + it)
+            continue
+        wrapped |= bool((neg._mkb_pool.cnt.to(torch.int32) > 1).any())
+        m.zero_grad(set_to_none=True)
+        loss = step(s, w, neg, mode)
+        ref = scoring.train_step_grads(tb, s.cpu(), neg.cpu(), w.cpu(), mode, 0.5, fast_norm=True)
+        np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+    assert wrapped, "the test is meant to exercise multiplicities > 1"
+
+
+def test_large_pool_falls_back_to_general_kernels():
+    """size > 512 is outside the pooled kernels: model(...) must silently take the general path, same numbers."""
+    from mkb_amd import datasets, losses, models, sampling
+    from mkb_amd.fused import pooled_supported
+    from oracle import scoring
+
+    ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(1)
+    m = models.TransE(hidden_dim=20, entities=ds.entities, relations=ds.relations, gamma=6.0)
+    tb = scoring.Tables("TransE", 20, 6.0, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone())
+    m = m.cuda()
+    K = 600
+    assert not pooled_supported(m, 8, K)
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    s = torch.tensor(ds.train[:8]).cuda()
+    neg = ns.generate(s, "tail-batch")
+    got = m(s, neg, "tail-batch")
+    ref = scoring.score(tb, s.cpu(), neg.cpu(), "tail-batch")
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=ATOL)
+    # and the oracle sampler agrees at this size too
+    from oracle import sampler as osamp
+    on = osamp.NegativeSampling(K, ds.train, ds.entities, ds.relations, seed=42)
+    want, _ = on.generate(s.cpu().numpy(), "tail-batch")
+    np.testing.assert_array_equal(neg.cpu().numpy(), want)
