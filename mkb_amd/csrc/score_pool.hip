@@ -2,6 +2,9 @@
 // mkb_pool_score_bwd).  The three tile kernels live in score_pool_kernels.h and are instantiated per model in
 // score_pool_<model>.hip (parallel compilation); see the header for the design.
 #include "score_pool_kernels.h"
+#include "gemm_mfma.h"
+
+#include <stdlib.h>
 
 namespace mkb {
 
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
 
 // ------------------------------------------------------------------------------------------------ host side
 struct Workspace {
-    float *Q, *dQ, *G, *dpos, *scratch;
+    float *Q, *dQ, *G, *dpos, *scratch, *gemm_part;
     size_t bytes;
 };
 
@@ -207,6 +210,13 @@ static int units_of(const mkb_tables_t *tb) { return tb->model == MKB_ROTATE ? t
 
 // Kernel configuration for a table shape: units per lane (vector width of the loads), waves per workgroup, and how
 // many workgroups share a row tile / position tile so that the grid fills 256 CUs with 16-32 waves each.
+// ComplEx / DistMult: the pair function is a dot product, so the pooled block is three dense fp32 GEMMs on the matrix
+// cores (gemm_mfma.h) instead of the lane-owns-dims VALU kernels.  MKB_POOL_NO_MFMA=1 keeps the VALU kernels (A/B).
+static bool use_mfma(const mkb_tables_t *tb) {
+    static const bool off = getenv("MKB_POOL_NO_MFMA") && getenv("MKB_POOL_NO_MFMA")[0] == '1';
+    return !off && (tb->model == MKB_COMPLEX || tb->model == MKB_DISTMULT) && tb->entity_dim >= 16;
+}
+
 static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch &L) {
     const int NU = units_of(tb);
     const int64_t De = tb->entity_dim, d = tb->hidden_dim;
@@ -227,7 +237,8 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     L.fwd_slices = clampi((target + row_tiles - 1) / row_tiles, 1, kMaxSlices);
-    L.q_slices = L.fwd_slices;
+    L.mfma = use_mfma(tb) ? 1 : 0;
+    L.q_slices = L.mfma ? 1 : L.fwd_slices;  // the GEMM writes complete dQ rows
     // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
     const int min_x = (int)((B + 255) / 256);
     L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
@@ -244,6 +255,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.G = take((size_t)B * P * 4);
     w.dpos = take((size_t)B * 4);
     w.scratch = take((size_t)(B + 1) * 4);
+    w.gemm_part = take(L.mfma ? (size_t)8 * B * (P > De ? P : De) * 4 : 0);  // split-K partials of the MFMA path
     w.bytes = off;
     return w;
 }
@@ -331,6 +343,13 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
                    1, tb->phase_div};
         if (int rc = dispatch_query_build(tb, head, ra, B, st)) return rc;
     }
+    if (use_mfma(tb)) {  // S = Q . ent[pool]^T on the matrix cores; every entry is written (cnt masks later)
+        GemmArgs g{};
+        g.A = w.Q; g.lda = tb->entity_dim; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
+        g.C = S; g.ldc = P; g.M = (int)B; g.N = (int)P; g.K = (int)tb->entity_dim; g.c0 = 0.f; g.c1 = 1.f;
+        ProfScope ps(MKB_PROF_POOL_FWD, st);
+        return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part);
+    }
     MKB_CHECK_HIP(hipMemsetAsync(S, 0, (size_t)B * P * 4, st));
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
     A.S = S;
@@ -341,16 +360,33 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
                       const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
                       bool chain_queries = true) {
-    PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
-    A.g_modulus = gr->g_modulus;
-    A.g_ent = gr->g_ent;
-    {
-        ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
-        if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;
-    }
-    {
-        ProfScope ps(MKB_PROF_POOL_BWD_X, st);
-        if (int rc = launcher_of(tb->model)(2, head, L, A, st)) return rc;
+    if (use_mfma(tb)) {
+        {   // dQ [B, De] = G [B, P] . ent[pool]
+            GemmArgs g{};
+            g.A = w.G; g.lda = P; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
+            g.C = w.dQ; g.ldc = tb->entity_dim; g.M = (int)B; g.N = (int)tb->entity_dim; g.K = (int)P;
+            ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+            if (int rc = launch_gemm<true, false, GEMM_STORE>(g, st, w.gemm_part)) return rc;
+        }
+        {   // g_ent[pool[p]] += (G^T [P, B] . Q [B, De])[p]
+            GemmArgs g{};
+            g.A = w.G; g.lda = P; g.B = w.Q; g.ldb = tb->entity_dim; g.b_idx = nullptr;
+            g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
+            ProfScope ps(MKB_PROF_POOL_BWD_X, st);
+            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st)) return rc;
+        }
+    } else {
+        PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
+        A.g_modulus = gr->g_modulus;
+        A.g_ent = gr->g_ent;
+        {
+            ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+            if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;
+        }
+        {
+            ProfScope ps(MKB_PROF_POOL_BWD_X, st);
+            if (int rc = launcher_of(tb->model)(2, head, L, A, st)) return rc;
+        }
     }
     if (chain_queries) {
         RowArgs ra{tb->ent, tb->rel, sample, w.dQ, gr->g_ent, gr->g_rel, tb->entity_dim, tb->relation_dim, tb->hidden_dim,

@@ -537,6 +537,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
 struct PoolLaunch {
     int kpt, nw;          // units per lane, waves per workgroup
     int fwd_slices, q_slices, x_slices;
+    int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
