@@ -233,12 +233,22 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     if (L.kpt == 1) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : 16);
     else if (L.kpt == 2) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : (lanes <= 512 ? 8 : 16));
     else L.nw = 16;
+    if (const char *e = getenv("MKB_POOL_CFG")) {  // experiment knob: "kpt,nw"
+        int k = 0, n = 0;
+        if (sscanf(e, "%d,%d", &k, &n) == 2 && (k == 1 || (k == 2 && even2) || (k == 4 && even4)) && (int64_t)k * n * 64 >= NU) {
+            L.kpt = k; L.nw = n;
+        }
+    }
+    // forward: 4 units per lane when the row allows it (measured 91 -> 77 us at the headline shape: the per-position
+    // wave reduction is amortised over twice the pair evaluations); the backward kernels gain nothing from it
+    L.fkpt = L.kpt; L.fnw = L.nw;
+    if (even4 && NU > 512 && NU <= 1024) { L.fkpt = 4; L.fnw = 4; }
     const int target = 256 * 16 / L.nw;  // workgroups for ~16 waves per CU
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    L.fwd_slices = clampi((target + row_tiles - 1) / row_tiles, 1, kMaxSlices);
+    L.fwd_slices = clampi((256 * 16 / L.fnw + row_tiles - 1) / row_tiles, 1, kMaxSlices);
     L.mfma = use_mfma(tb) ? 1 : 0;
-    L.q_slices = L.mfma ? 1 : L.fwd_slices;  // the GEMM writes complete dQ rows
+    L.q_slices = L.mfma ? 1 : clampi((target + row_tiles - 1) / row_tiles, 1, kMaxSlices);  // GEMM: complete dQ rows
     // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
     const int min_x = (int)((B + 255) / 256);
     L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);

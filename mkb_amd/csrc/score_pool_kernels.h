@@ -535,7 +535,8 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
 
 // ------------------------------------------------------------------------------------------------ launch helpers
 struct PoolLaunch {
-    int kpt, nw;          // units per lane, waves per workgroup
+    int kpt, nw;          // units per lane, waves per workgroup (backward kernels)
+    int fkpt, fnw;        // the same for the forward kernel (it amortises its wave reduction over more units per lane)
     int fwd_slices, q_slices, x_slices;
     int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
 };
@@ -568,7 +569,9 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
 }
 
 template <int MODEL, bool HEAD>
-static int launch_head(int which, const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
+    PoolLaunch L = L0;
+    if (which == 0) { L.kpt = L0.fkpt; L.nw = L0.fnw; }
     if (L.kpt == 1 && L.nw == 2) return launch_cfg<MODEL, HEAD, 1, 2>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 4) return launch_cfg<MODEL, HEAD, 1, 4>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 16) return launch_cfg<MODEL, HEAD, 1, 16>(which, L, A, st);
@@ -576,6 +579,7 @@ static int launch_head(int which, const PoolLaunch &L, const PoolArgs &A, hipStr
     if (L.kpt == 2 && L.nw == 4) return launch_cfg<MODEL, HEAD, 2, 4>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 8) return launch_cfg<MODEL, HEAD, 2, 8>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 16) return launch_cfg<MODEL, HEAD, 2, 16>(which, L, A, st);
+    if (L.kpt == 4 && L.nw == 4) return launch_cfg<MODEL, HEAD, 4, 4>(which, L, A, st);
     if (L.kpt == 4 && L.nw == 16) return launch_cfg<MODEL, HEAD, 4, 16>(which, L, A, st);
     return set_error(MKB_ERR_UNSUPPORTED, "no pooled kernel configuration (kpt=%d, nw=%d)", L.kpt, L.nw);
 }
