@@ -225,13 +225,13 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const bool even2 = al16 && NU % 2 == 0 && De % 2 == 0 && (!cp || d % 2 == 0);
     const bool even4 = al16 && NU % 4 == 0 && De % 4 == 0 && (!cp || d % 4 == 0);
     // units per lane: vector loads + packed math need even dims; waves: smallest workgroup that covers the row
-    if (even2 && NU >= 128 && NU <= 2048) L.kpt = 2;
+    if (even2 && NU >= 64 && NU <= 2048) L.kpt = 2;
     else if (even4 && NU > 2048 && NU <= 4096) L.kpt = 4;
     else if (NU <= 1024) L.kpt = 1;
     else return false;
     const int lanes = (NU + L.kpt - 1) / L.kpt;
-    if (L.kpt == 1) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : 16);
-    else if (L.kpt == 2) L.nw = lanes <= 128 ? 2 : (lanes <= 256 ? 4 : (lanes <= 512 ? 8 : 16));
+    if (L.kpt == 1) L.nw = lanes <= 64 ? 1 : (lanes <= 128 ? 2 : (lanes <= 256 ? 4 : 16));
+    else if (L.kpt == 2) L.nw = lanes <= 64 ? 1 : (lanes <= 128 ? 2 : (lanes <= 256 ? 4 : (lanes <= 512 ? 8 : 16)));
     else L.nw = 16;
     if (const char *e = getenv("MKB_POOL_CFG")) {  // experiment knob: "kpt,nw"
         int k = 0, n = 0;
@@ -252,6 +252,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
     const int min_x = (int)((B + 255) / 256);
     L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
+    if (const char *e = getenv("MKB_POOL_XSLICES")) { const int v = atoi(e); if (v >= min_x && v >= 1) L.x_slices = v; }
     return true;
 }
 

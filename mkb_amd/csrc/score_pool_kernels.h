@@ -144,10 +144,15 @@ template <int MODEL, bool HEAD, int KPT, int NW>
 __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // sized by the launch: 3 * P words
+    // position slice of this workgroup: p = slice + nslices * i (interleaved, so every slice gets the same share of the
+    // low, heavily used positions); only those are listed: LDS (and the list-building work) shrink with the slices
+    const int nsl = gridDim.y, sl = blockIdx.y;
+    const int Pn = (A.P - sl + nsl - 1) / nsl;
+    const int Pcap = (A.P + nsl - 1) / nsl;
+    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // sized by the launch: 3 * ceil(P / nslices) words
     int *s_row = lds_dyn;                                           // entity id per active position
-    int *s_pos = lds_dyn + A.P;                                     // pool position
-    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + 2 * A.P);  // bit r: row r of the tile uses it
+    int *s_pos = lds_dyn + Pcap;                                    // pool position
+    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + 2 * Pcap);  // bit r: row r of the tile uses it
     __shared__ float s_part[2][kSlab][NW][TI];  // wave totals, double buffered
     __shared__ int s_wave_cnt[NW];
 
@@ -158,10 +163,10 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
 
     // positions used by at least one row of the tile, compacted into LDS
     int n_act = 0;
-    for (int base = 0; base < A.P; base += WG) {
-        const int p = base + tid;
+    for (int base = 0; base < Pn; base += WG) {
+        const int p = sl + (base + tid) * nsl;
         unsigned m_own = 0;
-        if (p < A.P) {
+        if (base + tid < Pn) {
             unsigned c[TI];
 #pragma unroll
             for (int r = 0; r < TI; ++r) c[r] = (i0 + r < A.B) ? A.cnt[(int64_t)(i0 + r) * A.P + p] : 0;
@@ -189,16 +194,14 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
         }
     }
 
-    // this workgroup's slice: active positions a = slice, slice + nslices, ...
-    const int nsl = gridDim.y, sl = blockIdx.y;
-    const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
+    const int n_mine = n_act;
     const int j_last = n_mine - 1;
 
     // Candidate rows stream through a kRing-deep register ring; loads are UNCONDITIONAL (index clamped to the last
     // position) so that the compiler can count outstanding loads instead of draining them.
     float xr0[kRing][KPT], xr1[kRing][KPT];
     auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
-        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
+        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[j]) * A.De;
         load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
     };
     if (n_mine > 0) {
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
         for (int s = 0; s < kRing; ++s) {
             const int j = jb + s;
             const int jj = j % kSlab, buf = (j / kSlab) & 1;
-            const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[sl + min(j, j_last) * nsl]) : 0u;
+            const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[min(j, j_last)]) : 0u;
             float x0[KPT], x1[KPT];
 #pragma unroll
             for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
@@ -246,9 +249,9 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
             if (j < n_mine && (jj == kSlab - 1 || j == j_last)) {  // wave-uniform: combine <= kSlab positions
                 __syncthreads();  // double-buffered s_part: one barrier per batch
                 const int j0 = j - jj, nb = jj + 1;
-                if (tid < nb * TI) {
-                    const int cj = tid / TI, r = tid % TI;
-                    const int a = sl + (j0 + cj) * nsl;
+                for (int e = tid; e < nb * TI; e += WG) {  // (a 1-wave workgroup has fewer lanes than entries)
+                    const int cj = e / TI, r = e % TI;
+                    const int a = j0 + cj;
                     if (s_mask[a] & (1u << r)) {
                         float sum = 0.f;
 #pragma unroll
@@ -269,12 +272,15 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     constexpr int WG = NW * 64;
     // ALL LDS is dynamic (10 * P + 32 words): a static __shared__ in front of the dynamic region can shift its base
     // off 16 bytes, and the ds_read_b128 of s_g would then be replayed (cdna guide, G17)
+    const int nsl = gridDim.y, sl = blockIdx.y;  // position slice: p = slice + nslices * i, as in the forward kernel
+    const int Pn = (A.P - sl + nsl - 1) / nsl;
+    const int Pcap = (A.P + nsl - 1) / nsl;
     extern __shared__ __attribute__((aligned(16))) int lds_dyn[];
-    float (*s_g)[TI] = reinterpret_cast<float (*)[TI]>(lds_dyn);   // [P][8] gradient seeds of the tile per active position
-    int *s_row = lds_dyn + TI * A.P;
-    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * A.P);
-    int *s_wave_cnt = lds_dyn + (TI + 2) * A.P;
-    float *s_red = reinterpret_cast<float *>(lds_dyn + (TI + 2) * A.P + 16);
+    float (*s_g)[TI] = reinterpret_cast<float (*)[TI]>(lds_dyn);   // [Pcap][8] gradient seeds per active position
+    int *s_row = lds_dyn + TI * Pcap;
+    unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * Pcap);
+    int *s_wave_cnt = lds_dyn + (TI + 2) * Pcap;
+    float *s_red = reinterpret_cast<float *>(lds_dyn + (TI + 2) * Pcap + 16);
 
     const int tid = threadIdx.x;
     const int i0 = blockIdx.x * TI;
@@ -282,13 +288,13 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     const int u0 = tid * KPT;
 
     int n_act = 0;
-    for (int base = 0; base < A.P; base += WG) {
-        const int p = base + tid;
+    for (int base = 0; base < Pn; base += WG) {
+        const int p = sl + (base + tid) * nsl;
         unsigned m_own = 0;
         float g_own[TI];
 #pragma unroll
         for (int r = 0; r < TI; ++r) g_own[r] = 0.f;
-        if (p < A.P) {
+        if (base + tid < Pn) {
             unsigned c[TI];
 #pragma unroll
             for (int r = 0; r < TI; ++r) {
@@ -325,12 +331,11 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
     float extra = 0.f;
 
-    const int nsl = gridDim.y, sl = blockIdx.y;
-    const int n_mine = (n_act > sl) ? (n_act - sl + nsl - 1) / nsl : 0;
+    const int n_mine = n_act;
     const int j_last = n_mine - 1;
     float xr0[kRing][KPT], xr1[kRing][KPT];
     auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
-        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[sl + j * nsl]) * A.De;
+        const float *x = A.ent + (int64_t)__builtin_amdgcn_readfirstlane(s_row[j]) * A.De;
         load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
     };
     if (n_mine > 0) {
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
 #pragma unroll
         for (int s = 0; s < kRing; ++s) {
             const int j = jb + s;
-            const int a = sl + min(j, j_last) * nsl;
+            const int a = min(j, j_last);
             const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[a]) : 0u;
             float g[TI];
 #pragma unroll
@@ -555,10 +560,10 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
     const dim3 block(NW * 64);
     if (which == 0) {
         dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.fwd_slices);
-        hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, (size_t)3 * A.P * 4, st, A);
+        hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, (size_t)3 * ((A.P + L.fwd_slices - 1) / L.fwd_slices) * 4, st, A);
     } else if (which == 1) {
         dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.q_slices);
-        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((size_t)(TI + 2) * A.P + 32) * 4, st, A);
+        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((size_t)(TI + 2) * ((A.P + L.q_slices - 1) / L.q_slices) + 32) * 4, st, A);
     } else {
         dim3 grid((unsigned)(((A.P + TI - 1) / TI) * L.x_slices));
         const size_t rows_per = (size_t)((A.B + L.x_slices - 1) / L.x_slices);
@@ -572,6 +577,8 @@ template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
     PoolLaunch L = L0;
     if (which == 0) { L.kpt = L0.fkpt; L.nw = L0.fnw; }
+    if (L.kpt == 1 && L.nw == 1) return launch_cfg<MODEL, HEAD, 1, 1>(which, L, A, st);
+    if (L.kpt == 2 && L.nw == 1) return launch_cfg<MODEL, HEAD, 2, 1>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 2) return launch_cfg<MODEL, HEAD, 1, 2>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 4) return launch_cfg<MODEL, HEAD, 1, 4>(which, L, A, st);
     if (L.kpt == 1 && L.nw == 16) return launch_cfg<MODEL, HEAD, 1, 16>(which, L, A, st);
