@@ -18,10 +18,11 @@ __all__ = ["FusedTrainStep", "pooled_forward", "pooled_supported"]
 _workspaces = {}
 
 
-def _workspace(model, B, K):
-    """Device scratch for the pooled kernels, cached per (device, table shape, B, K)."""
+def _workspace(model, B, K, slot=0):
+    """Device scratch for the pooled kernels, cached per (device, table shape, B, K, slot); ``slot`` separates the
+    micro-batches of one step, whose forward scratch must survive until their backward half runs."""
     dev = model.entity_embedding.device
-    key = (dev, model.name, model.entity_dim, B, K)
+    key = (dev, model.name, model.entity_dim, B, K, slot)
     ws = _workspaces.get(key)
     if ws is None:
         n = _hip.lib().mkb_pool_step_workspace_bytes(model._tables(), B, K)

@@ -204,15 +204,20 @@ def gather_dims(local, group=None):
 class DimShardedStep:
     """The fused training step (mkb_amd.fused.FusedTrainStep) over a dimension-sharded model: forward half on the
     local dims, ONE all-reduce of the partial scores, backward half on the local dims.  Every rank must be given
-    the same (global) batch and draw the same negatives (same sampler seed)."""
+    the same (global) batch and draw the same negatives (same sampler seed).
 
-    def __init__(self, local_model, alpha, group=None):
+    ``micro_batches`` (default 2 when there is more than one rank) splits the rows of the batch so that the
+    all-reduce of one part's scores runs on RCCL's stream while the other part's forward / backward kernels run:
+    [fwd 0][fwd 1 | all-reduce 0][bwd 0 | all-reduce 1][bwd 1].  The loss normaliser W is the whole batch's."""
+
+    def __init__(self, local_model, alpha, group=None, micro_batches=None):
         from . import _hip
         from .fused import _workspace
 
         self._hip, self._workspace = _hip, _workspace
         self.model, self.alpha, self.group = local_model, float(alpha), group
         self.rank, self.world, self.gamma, self.uses_gamma = local_model._dim_shard
+        self.micro_batches = (2 if self.world > 1 else 1) if micro_batches is None else micro_batches
 
     def __call__(self, sample, weight, negative_sample, mode):
         _hip, m = self._hip, self.model
@@ -222,10 +227,6 @@ class DimShardedStep:
         weight = _hip.contiguous(weight, torch.float32)
         B, K = sample.shape[0], info.size
         dev = sample.device
-        scores = torch.empty(B * (2 * K + 1), dtype=torch.float32, device=dev)  # [pos | pool]: one all-reduce
-        pos, S = scores[:B], scores[B:].view(B, 2 * K)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        ws = self._workspace(m, B, K)
         params = [m.entity_embedding, m.relation_embedding] + ([m.modulus] if m.name == "pRotatE" else [])
         for p in params:
             if p.grad is None:
@@ -239,19 +240,39 @@ class DimShardedStep:
             lazy.catch_up(ent, ids)
             ent._mkb_touched = ids
         lib, tb = _hip.lib(), m._tables()
+        nmb = max(1, min(self.micro_batches, B // 8))
+        bounds = [(B * i // nmb, B * (i + 1) // nmb) for i in range(nmb)]
+        wsum = weight.sum().reshape(1) if nmb > 1 else None          # W of the WHOLE batch (every rank has all rows)
+        parts, works = [], []
         with torch.cuda.device(dev):
-            _hip.check(lib.mkb_pool_step_fwd(tb, _hip.ptr(sample), _hip.ptr(info.pool), _hip.ptr(info.cnt), B, K, mode_id,
-                                             _hip.ptr(pos), _hip.ptr(S), _hip.ptr(ws), _hip.stream_ptr()),
-                       "mkb_pool_step_fwd")
-        if self.world > 1:
-            dist.all_reduce(scores, group=self.group)
-        if self.uses_gamma:
-            scores += self.gamma
-        with torch.cuda.device(dev):
-            _hip.check(lib.mkb_pool_step_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
-                                             _hip.ptr(info.cnt), B, K, mode_id, self.alpha, None, _hip.ptr(pos), _hip.ptr(S),
-                                             _hip.ptr(loss), _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_step_bwd")
+            for lo, hi in bounds:                                     # forward halves + their all-reduces (async)
+                b = hi - lo
+                scores = torch.empty(b * (2 * K + 1), dtype=torch.float32, device=dev)  # [pos | pool]: one collective
+                pos, S = scores[:b], scores[b:].view(b, 2 * K)
+                ws = self._workspace(m, b, K, slot=len(parts))
+                _hip.check(lib.mkb_pool_step_fwd(tb, _hip.ptr(sample[lo:hi]), _hip.ptr(info.pool), _hip.ptr(info.cnt[lo:hi]),
+                                                 b, K, mode_id, _hip.ptr(pos), _hip.ptr(S), _hip.ptr(ws),
+                                                 _hip.stream_ptr()), "mkb_pool_step_fwd")
+                works.append(dist.all_reduce(scores, group=self.group, async_op=True) if self.world > 1 else None)
+                parts.append((lo, hi, scores, pos, S, ws))
+            total = None
+            for (lo, hi, scores, pos, S, ws), work in zip(parts, works):  # backward halves as their scores arrive
+                b = hi - lo
+                if work is not None:
+                    work.wait()
+                if self.uses_gamma:
+                    scores += self.gamma
+                loss = torch.empty(1, dtype=torch.float32, device=dev)
+                _hip.check(lib.mkb_pool_step_bwd(tb, gr, _hip.ptr(sample[lo:hi]), _hip.ptr(weight[lo:hi]), _hip.ptr(info.pool),
+                                                 _hip.ptr(info.cnt[lo:hi]), b, K, mode_id, self.alpha, _hip.ptr(wsum),
+                                                 _hip.ptr(pos), _hip.ptr(S), _hip.ptr(loss), _hip.ptr(ws),
+                                                 _hip.stream_ptr()), "mkb_pool_step_bwd")
+                total = loss if total is None else total + loss
         if m.name == "pRotatE" and self.world > 1:
             dist.all_reduce(m.modulus.grad, group=self.group)  # the modulus is replicated: its gradient sums over dims
-        self.positive_score, self._S, self._info = pos.view(B, 1), S, info
-        return loss.reshape(())
+        self._parts, self._info = parts, info
+        return total.reshape(())
+
+    @property
+    def positive_score(self):
+        return torch.cat([p[3] for p in self._parts]).view(-1, 1)
