@@ -325,3 +325,51 @@ def test_large_pool_falls_back_to_general_kernels():
     on = osamp.NegativeSampling(K, ds.train, ds.entities, ds.relations, seed=42)
     want, _ = on.generate(s.cpu().numpy(), "tail-batch")
     np.testing.assert_array_equal(neg.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("name,hidden", [("RotatE", 1000), ("ComplEx", 1000), ("TransE", 1000)])
+def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name, hidden):
+    """BASELINE full size (FB15k-237, hidden 1000, K=256, B=1024): the oracle needs ~80 s per step here, so
+    (a) the fused pooled step is checked against the GENERAL kernels (an independent implementation: per-row LDS
+        query + wave-per-candidate forward, atomics backward) on every score, the loss and both dense gradients;
+    (b) the oracle itself checks a 12-row slice of the same batch (scores), and the loss is recomputed from the
+        step's own scores with torch ops (losses/adversarial.py:21-30 formula)."""
+    from mkb_amd import datasets, losses, models, sampling
+    from mkb_amd.fused import FusedTrainStep
+    from oracle import scoring
+
+    ds = datasets.Fb15k237(batch_size=1024, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(42)
+    m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=9.0)
+    tb = scoring.Tables(name, hidden, 9.0, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(),
+                        m.modulus.detach().clone() if hasattr(m, "modulus") else None)
+    m = m.cuda()
+    ns = sampling.NegativeSampling(size=256, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64))
+    idx = torch.as_tensor(np.random.RandomState(5).randint(len(train), size=1024))
+    s, w = train[idx].cuda(), (torch.rand(1024) + 0.1).cuda()
+    for mode in ("head-batch", "tail-batch"):
+        neg = ns.generate(s, mode)
+        m.zero_grad(set_to_none=True)
+        step = FusedTrainStep(m, alpha=1.0)
+        loss = step(s, w, neg, mode)
+        pos_f, neg_f = step.positive_score.clone(), step.negative_score.clone()
+        g_f = (m.entity_embedding.grad.clone(), m.relation_embedding.grad.clone())
+        # (a) general kernels through autograd on a plain copy of the negatives
+        m.zero_grad(set_to_none=True)
+        plain = neg.clone()
+        pos_g, neg_g = m(s), m(s, plain, mode)
+        err = losses.Adversarial(alpha=1.0)(pos_g, neg_g, w)
+        err.backward()
+        np.testing.assert_allclose(pos_f.cpu().numpy(), pos_g.detach().cpu().numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(neg_f.cpu().numpy(), neg_g.detach().cpu().numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(loss.item(), err.item(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(g_f[0].cpu().numpy(), m.entity_embedding.grad.cpu().numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(g_f[1].cpu().numpy(), m.relation_embedding.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        # (b) oracle on a slice + the loss formula on the step's own scores
+        rows = torch.arange(0, 1024, 93)[:12]
+        ref = scoring.score(tb, s[rows.cuda()].cpu(), neg[rows.cuda()].cpu(), mode, fast_norm=True)
+        np.testing.assert_allclose(neg_f[rows.cuda()].cpu().numpy(), ref.numpy(), rtol=0, atol=ATOL)
+        ref_loss = scoring.adversarial(pos_f.cpu(), neg_f.cpu(), w.cpu(), 1.0)
+        np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=0, atol=1e-5)
+    ns.check()
