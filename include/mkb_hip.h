@@ -184,9 +184,10 @@ int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode,
 /* ---- per-kernel timing (measurement aid, no reference counterpart) -------------------------------------
  * When enabled, the launches of the named kernel class are bracketed by hipEvents recorded on the SAME stream
  * the kernel is launched on.  mkb_profile_read synchronises, returns the number of bracketed launches and
- * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward (dq pass),
+ * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward (the dq and dx passes
+ * in one launch; for ComplEx / DistMult the dQ GEMM),
  * 1 = pooled forward, 2 = Adam, 3 = sampler (draw + filter), 4 = adversarial loss, 5 = general forward,
- * 6 = general backward, 7 = pooled backward (dx pass).  At most 8192 launches are kept between reads.
+ * 6 = general backward, 7 = pooled backward dx pass when it is launched alone (the GEMM route, MKB_POOL_SPLIT_BWD).  At most 8192 launches are kept between reads.
  */
 #define MKB_PROF_POOL_BWD_Q 0
 #define MKB_PROF_POOL_FWD 1

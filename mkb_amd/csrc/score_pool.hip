@@ -213,7 +213,8 @@ static int units_of(const mkb_tables_t *tb) { return tb->model == MKB_ROTATE ? t
 // ComplEx / DistMult: the pair function is a dot product, so the pooled block is three dense fp32 GEMMs on the matrix
 // cores (gemm_mfma.h) instead of the lane-owns-dims VALU kernels.  MKB_POOL_NO_MFMA=1 keeps the VALU kernels (A/B).
 static bool use_mfma(const mkb_tables_t *tb) {
-    static const bool off = getenv("MKB_POOL_NO_MFMA") && getenv("MKB_POOL_NO_MFMA")[0] == '1';
+    const char *e = getenv("MKB_POOL_NO_MFMA");  // read per call: the tests switch it within one process
+    const bool off = e && e[0] == '1';
     return !off && (tb->model == MKB_COMPLEX || tb->model == MKB_DISTMULT) && tb->entity_dim >= 16;
 }
 
@@ -252,6 +253,8 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
     const int min_x = (int)((B + 255) / 256);
     L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
+    if (const char *e = getenv("MKB_POOL_FSLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd_slices = v; }
+    if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma) L.q_slices = v; }
     if (const char *e = getenv("MKB_POOL_XSLICES")) { const int v = atoi(e); if (v >= min_x && v >= 1) L.x_slices = v; }
     return true;
 }
@@ -271,15 +274,24 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     return w;
 }
 
+#ifdef MKB_TRACE_WG
+static unsigned long long *g_trace = nullptr;
+static int g_trace_kind = 2;
+extern "C" void mkb_debug_set_trace(void *p, int kind) { g_trace = (unsigned long long *)p; g_trace_kind = kind; }
+#endif
+
 static PoolArgs make_args(const mkb_tables_t *tb, const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t P,
                           const Workspace &w, const PoolLaunch &L) {
     PoolArgs A{};
     A.ent = tb->ent; A.Q = w.Q; A.pool = pool; A.cnt = cnt; A.G = w.G; A.dQ = w.dQ;
     A.B = (int)B; A.P = (int)P; A.d = tb->hidden_dim; A.De = tb->entity_dim; A.kd = tb->phase_div;
-    A.modulus = tb->modulus; A.x_slices = L.x_slices;
+    A.modulus = tb->modulus; A.x_slices = L.x_slices; A.q_slices = L.q_slices;
     const bool g = tb->model == MKB_TRANSE || tb->model == MKB_ROTATE || tb->model == MKB_PROTATE;
     A.c0 = g ? tb->gamma : 0.f;
     A.c1 = g ? -1.f : 1.f;
+#ifdef MKB_TRACE_WG
+    A.trace = g_trace; A.trace_kind = g_trace_kind;
+#endif
     return A;
 }
 
@@ -390,11 +402,15 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
         A.g_modulus = gr->g_modulus;
         A.g_ent = gr->g_ent;
-        {
+        static const bool split = getenv("MKB_POOL_SPLIT_BWD") != nullptr;  // A/B: the two passes as two launches
+        if (!split) {  // dq and dx passes in one grid (pool_bwd_kernel); profiled as the POOL_BWD_Q class
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
             if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;
-        }
-        {
+        } else {
+            {
+                ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+                if (int rc = launcher_of(tb->model)(3, head, L, A, st)) return rc;
+            }
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
             if (int rc = launcher_of(tb->model)(2, head, L, A, st)) return rc;
         }

@@ -24,6 +24,7 @@
 // KPT = 2 / 4 lanes load float2 / float4 and give the compiler pairs of units to pack into v_pk_* ops.
 // VALU-bound by design (RotatE: one v_sqrt / v_rsq per (row, slot, complex dim)).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "model_math.h"
 
@@ -31,6 +32,7 @@ namespace mkb {
 
 constexpr int TI = 8;       // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
 constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions / rows in flight per lane)
+constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8 rows / positions takes the branch-free body
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 1024; // pool positions supported by the LDS tile lists
 constexpr int kMaxSlices = 8;
@@ -46,10 +48,36 @@ struct PoolArgs {
     float *g_ent;          // [N, De] table gradient (backward, x pass adds into it)
     float *g_modulus;      // pRotatE
     const float *modulus;  // pRotatE
-    int B, P, d, x_slices;
+    int B, P, d, x_slices, q_slices;
+    int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
+#ifdef MKB_TRACE_WG
+    unsigned long long *trace;  // tools/wgtrace.py: 8 words per workgroup (timestamps, hardware id, work)
+    int trace_kind;             // which kernel records: 0 fwd, 1 bwd_q, 2 bwd_x
+#endif
 };
+
+#ifdef MKB_TRACE_WG
+#define MKB_TRACE_T(var) const unsigned long long var = wall_clock64()
+#define MKB_TRACE_OUT(A, kind, t0, t1, t2, work)                                                    \
+    if (threadIdx.x == 0 && (A).trace && ((A).trace_kind == (kind) || (A).trace_kind == 3)) {                                                            \
+        unsigned long long *tr = (A).trace + ((A).trace_kind == 3 ? 8ull * 4096 * (kind) : 0ull) + 8ull * (blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y); \
+        unsigned hw = 0, xcc = 0;                                                                   \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                           \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                         \
+        tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = wall_clock64();                                 \
+        tr[4] = hw; tr[5] = xcc; tr[6] = (unsigned long long)(work); tr[7] = blockIdx.x;            \
+    }
+#else
+#define MKB_TRACE_T(var)
+#define MKB_TRACE_OUT(A, kind, t0, t1, t2, work)
+#endif
+
+// a value every lane of the wave holds identically -> scalar register
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
 // exclusive scan of a flag over the NW-wave workgroup; returns this lane's slot, *total = count.
 // Contains one barrier; callers put another one before the next call (wave_cnt is reused).
@@ -162,6 +190,7 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
     const int u0 = tid * KPT;
 
     // positions used by at least one row of the tile, compacted into LDS
+    MKB_TRACE_T(tr_t0);
     int n_act = 0;
     for (int base = 0; base < Pn; base += WG) {
         const int p = sl + (base + tid) * nsl;
@@ -194,6 +223,7 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
         }
     }
 
+    MKB_TRACE_T(tr_t1);
     const int n_mine = n_act;
     const int j_last = n_mine - 1;
 
@@ -219,26 +249,34 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
             for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
             load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
             float part[TI];
+            // Two bodies: the branch-free one evaluates all 8 rows as one basic block (independent chains interleave,
+            // no per-row scalar branch); rows that do not use the position are computed and never stored.  Positions
+            // only a few rows use keep the per-row branches.
+            auto rows = [&](auto dense_c) {
+                constexpr bool DENSE = decltype(dense_c)::value;
 #pragma unroll
-            for (int r = 0; r < TI; ++r) {
-                part[r] = 0.f;
-                if (m & (1u << r)) {  // out-of-range units hold q = x = 0 and contribute exactly 0
-                    if constexpr (CP && KPT % 2 == 0) {
-                        f2 acc = f2{0.f, 0.f};
+                for (int r = 0; r < TI; ++r) {
+                    part[r] = 0.f;
+                    if (DENSE || (m & (1u << r))) {  // out-of-range units hold q = x = 0 and contribute exactly 0
+                        if constexpr (CP && KPT % 2 == 0) {
+                            f2 acc = f2{0.f, 0.f};
 #pragma unroll
-                        for (int v = 0; v < KPT; v += 2)
-                            acc += pair_term_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
-                                                   f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]});
-                        part[r] = acc.x + acc.y;
-                    } else {
+                            for (int v = 0; v < KPT; v += 2)
+                                acc += pair_term_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
+                                                       f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]});
+                            part[r] = acc.x + acc.y;
+                        } else {
 #pragma unroll
-                        for (int v = 0; v < KPT; ++v) {
-                            if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
-                            else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                            for (int v = 0; v < KPT; ++v) {
+                                if constexpr (CP) part[r] += pair_term_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]});
+                                else part[r] += pair_term_real<MODEL, HEAD>(q0[r][v], x0[v], A.kd);
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (__builtin_popcount(m) >= kDense) rows(std::true_type{});
+            else rows(std::false_type{});
             float t0, t1;
             reduce8_wave(part, t0, t1);
             if ((lane & 15) == 0) {
@@ -263,19 +301,21 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
             }
         }
     }
+    MKB_TRACE_OUT(A, 0, tr_t0, tr_t1, wall_clock64(), n_mine);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq
+// Body of one (row tile, position slice) workgroup of the merged backward kernel (pool_bwd_kernel below).
 template <int MODEL, bool HEAD, int KPT, int NW>
-__global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
+__device__ __forceinline__ void pool_bwd_q_body(const PoolArgs &A, const int block, int *lds_dyn) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
     // ALL LDS is dynamic (10 * P + 32 words): a static __shared__ in front of the dynamic region can shift its base
     // off 16 bytes, and the ds_read_b128 of s_g would then be replayed (cdna guide, G17)
-    const int nsl = gridDim.y, sl = blockIdx.y;  // position slice: p = slice + nslices * i, as in the forward kernel
+    const int row_tiles = (A.B + TI - 1) / TI;
+    const int nsl = A.q_slices, sl = block / row_tiles;  // position slice: p = slice + nslices * i, as in the forward kernel
     const int Pn = (A.P - sl + nsl - 1) / nsl;
     const int Pcap = (A.P + nsl - 1) / nsl;
-    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];
     float (*s_g)[TI] = reinterpret_cast<float (*)[TI]>(lds_dyn);   // [Pcap][8] gradient seeds per active position
     int *s_row = lds_dyn + TI * Pcap;
     unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * Pcap);
@@ -283,10 +323,11 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     float *s_red = reinterpret_cast<float *>(lds_dyn + (TI + 2) * Pcap + 16);
 
     const int tid = threadIdx.x;
-    const int i0 = blockIdx.x * TI;
+    const int i0 = (block - sl * row_tiles) * TI;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
 
+    MKB_TRACE_T(tr_t0);
     int n_act = 0;
     for (int base = 0; base < Pn; base += WG) {
         const int p = sl + (base + tid) * nsl;
@@ -303,7 +344,10 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
                 g_own[r] = in ? A.G[(int64_t)(i0 + r) * A.P + p] : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < TI; ++r) m_own |= (c[r] != 0) ? (1u << r) : 0u;
+            for (int r = 0; r < TI; ++r) {
+                m_own |= (c[r] != 0) ? (1u << r) : 0u;
+                g_own[r] = (c[r] != 0) ? g_own[r] : 0.f;  // the branch-free body relies on g = 0 for unused pairs
+            }
         }
         int tot;
         const int slot = n_act + wg_compact_slot<NW>(m_own != 0, s_wave_cnt, &tot);
@@ -331,6 +375,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
     float extra = 0.f;
 
+    MKB_TRACE_T(tr_t1);
     const int n_mine = n_act;
     const int j_last = n_mine - 1;
     float xr0[kRing][KPT], xr1[kRing][KPT];
@@ -350,46 +395,57 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
             const unsigned m = (j < n_mine) ? __builtin_amdgcn_readfirstlane(s_mask[a]) : 0u;
             float g[TI];
 #pragma unroll
-            for (int r = 0; r < TI; ++r) g[r] = s_g[a][r];  // two ds_read_b128, same address in every lane
+            for (int r = 0; r < TI; ++r) g[r] = uniform_f32(s_g[a][r]);  // two ds_read_b128, same address in every lane -> SGPRs
             float x0[KPT], x1[KPT];
 #pragma unroll
             for (int v = 0; v < KPT; ++v) { x0[v] = xr0[s][v]; x1[v] = xr1[s][v]; }
             load_x(min(j + kRing, j_last), xr0[s], xr1[s]);
+            // branch-free body for positions most rows use (see the forward kernel): unused pairs carry g = 0 and add 0
+            auto rows = [&](auto dense_c) {
+                constexpr bool DENSE = decltype(dense_c)::value;
 #pragma unroll
-            for (int r = 0; r < TI; ++r) {
-                if (m & (1u << r)) {
-                    if constexpr (CP && KPT % 2 == 0) {
+                for (int r = 0; r < TI; ++r) {
+                    if (DENSE || (m & (1u << r))) {
+                        if constexpr (CP && KPT % 2 == 0) {
 #pragma unroll
-                        for (int v = 0; v < KPT; v += 2) {
-                            f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
-                            pair_bwd_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]}, f2{x0[v], x0[v + 1]},
-                                           f2{x1[v], x1[v + 1]}, g[r], ar, ai);
-                            dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
-                            dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
-                        }
-                    } else
+                            for (int v = 0; v < KPT; v += 2) {
+                                f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
+                                pair_bwd_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]}, f2{x0[v], x0[v + 1]},
+                                               f2{x1[v], x1[v + 1]}, g[r], ar, ai);
+                                dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
+                                dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
+                            }
+                        } else
 #pragma unroll
-                    for (int v = 0; v < KPT; ++v) {
-                        if constexpr (CP) {
-                            Cplx dq, dx;
-                            pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
-                            dq0[r][v] += dq.re;
-                            dq1[r][v] += dq.im;
-                        } else {
-                            float dq, dx, e0 = 0.f;
-                            pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
-                            dq0[r][v] += dq;
-                            extra += g[r] * e0;
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) {
+                                Cplx dq, dx;
+                                pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
+                                dq0[r][v] += dq.re;
+                                dq1[r][v] += dq.im;
+                            } else {
+                                float dq, dx, e0 = 0.f;
+                                pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
+                                dq0[r][v] += dq;
+                                extra += g[r] * e0;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (__builtin_popcount(m) >= kDense) rows(std::true_type{});
+            else rows(std::false_type{});
         }
     }
+    MKB_TRACE_T(tr_t2);
     float *dQs = A.dQ + (int64_t)sl * A.B * A.De;
 #pragma unroll
     for (int r = 0; r < TI; ++r)
+#ifdef MKB_EXP_NO_DQ_STORE
+        if (i0 + r < A.B && A.P < 0) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
+#else
         if (i0 + r < A.B) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
+#endif
     if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
         extra = wave_sum(extra);
         if ((tid & 63) == 0) s_red[tid >> 6] = extra;
@@ -400,20 +456,29 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_q_kernel(PoolArgs A) {
             atomicAdd(A.g_modulus, -s);
         }
     }
+    MKB_TRACE_OUT(A, 1, tr_t0, tr_t1, tr_t2, n_mine);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dx
 template <int MODEL, bool HEAD, int KPT, int NW>
-__global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
+__device__ __forceinline__ void pool_bwd_x_body(const PoolArgs &A, const int block, int *lds_dyn) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // all LDS dynamic: 10 * rows_per + 16 words
+    // all LDS dynamic: 10 * rows_per + 16 words
 
     const int tid = threadIdx.x;
     // 1-D grid, tile-major: the workgroups of the low position tiles (used by every row: the heavy ones) are
     // dispatched first; the light / empty tiles fill in behind them.
-    const int nsl = A.x_slices, sl = blockIdx.x % nsl;
-    const int p0 = (blockIdx.x / nsl) * TI;
+    // ... except the fringe: the first tiles past position P / 2 (every row takes its first P / 2 surviving candidates,
+    // so those tiles are used by the rows the filter hit, a few positions each).  Their workgroups are latency-bound
+    // (little math per streamed query row) and starve when they share a CU with an older heavy workgroup -- the CU
+    // issues oldest-first -- so they are dispatched FIRST: measured tail 103 -> 78 us at the headline shape.
+    const int nsl = A.x_slices, sl = block % nsl;
+    const int n_tiles = (A.P + TI - 1) / TI, heavy_tiles = min(n_tiles, (A.P / 2 + TI - 1) / TI);
+    const int fringe = min(2, n_tiles - heavy_tiles);
+    const int bt = block / nsl;
+    const int tile = bt < fringe ? heavy_tiles + bt : (bt < heavy_tiles + fringe ? bt - fringe : bt);
+    const int p0 = tile * TI;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
     const int rows_per = (A.B + nsl - 1) / nsl;
@@ -422,6 +487,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
     int *s_i = lds_dyn + TI * rows_per;                                   // batch rows of the slice that use the tile
     unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * rows_per);  // bit t: row uses position p0 + t
     int *s_wave_cnt = lds_dyn + (TI + 2) * rows_per;
+    MKB_TRACE_T(tr_t0);
 
     int n_rows = 0;
     for (int base = r_lo; base < r_hi; base += WG) {
@@ -435,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
             for (int t = 0; t < TI; ++t) {
                 if (p0 + t < A.P) {
                     const unsigned c = A.cnt[(int64_t)i_own * A.P + p0 + t];
-                    g_own[t] = A.G[(int64_t)i_own * A.P + p0 + t];
+                    g_own[t] = (c != 0) ? A.G[(int64_t)i_own * A.P + p0 + t] : 0.f;  // g = 0: the branch-free body adds 0
                     m_own |= (c != 0) ? (1u << t) : 0u;
                 }
             }
@@ -452,6 +518,7 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
         __syncthreads();
     }
 
+    MKB_TRACE_T(tr_t1);
     float x0[TI][KPT], x1[TI][KPT], dx0[TI][KPT], dx1[TI][KPT];
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
@@ -484,41 +551,48 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
             const unsigned m = (j < n_rows) ? __builtin_amdgcn_readfirstlane(s_mask[jc]) : 0u;
             float g[TI];
 #pragma unroll
-            for (int t = 0; t < TI; ++t) g[t] = s_g[jc][t];
+            for (int t = 0; t < TI; ++t) g[t] = uniform_f32(s_g[jc][t]);  // wave-uniform: keep the seeds in SGPRs
             float q0[KPT], q1[KPT];
 #pragma unroll
             for (int v = 0; v < KPT; ++v) { q0[v] = qr0[s][v]; q1[v] = qr1[s][v]; }
             load_q(min(j + kRing, j_last), qr0[s], qr1[s]);
+            // branch-free body for rows that use most of the tile (see the forward kernel): unused pairs carry g = 0
+            auto positions = [&](auto dense_c) {
+                constexpr bool DENSE = decltype(dense_c)::value;
 #pragma unroll
-            for (int t = 0; t < TI; ++t) {
-                if (m & (1u << t)) {
-                    if constexpr (CP && KPT % 2 == 0) {  // accumulates -dx (the dq sign); negated once at the store
+                for (int t = 0; t < TI; ++t) {
+                    if (DENSE || (m & (1u << t))) {
+                        if constexpr (CP && KPT % 2 == 0) {  // accumulates -dx (the dq sign); negated once at the store
 #pragma unroll
-                        for (int v = 0; v < KPT; v += 2) {
-                            f2 ar = f2{dx0[t][v], dx0[t][v + 1]}, ai = f2{dx1[t][v], dx1[t][v + 1]};
-                            pair_bwd_cmod2(f2{q0[v], q0[v + 1]}, f2{q1[v], q1[v + 1]}, f2{x0[t][v], x0[t][v + 1]},
-                                           f2{x1[t][v], x1[t][v + 1]}, g[t], ar, ai);
-                            dx0[t][v] = ar.x; dx0[t][v + 1] = ar.y;
-                            dx1[t][v] = ai.x; dx1[t][v + 1] = ai.y;
-                        }
-                    } else
+                            for (int v = 0; v < KPT; v += 2) {
+                                f2 ar = f2{dx0[t][v], dx0[t][v + 1]}, ai = f2{dx1[t][v], dx1[t][v + 1]};
+                                pair_bwd_cmod2(f2{q0[v], q0[v + 1]}, f2{q1[v], q1[v + 1]}, f2{x0[t][v], x0[t][v + 1]},
+                                               f2{x1[t][v], x1[t][v + 1]}, g[t], ar, ai);
+                                dx0[t][v] = ar.x; dx0[t][v + 1] = ar.y;
+                                dx1[t][v] = ai.x; dx1[t][v + 1] = ai.y;
+                            }
+                        } else
 #pragma unroll
-                    for (int v = 0; v < KPT; ++v) {
-                        if constexpr (CP) {
-                            Cplx dq, dx;
-                            pair_bwd_cmod(Cplx{q0[v], q1[v]}, Cplx{x0[t][v], x1[t][v]}, g[t], dq, dx);
-                            dx0[t][v] += dx.re;
-                            dx1[t][v] += dx.im;
-                        } else {
-                            float dq, dx, e0 = 0.f;
-                            pair_bwd_real<MODEL, HEAD>(q0[v], x0[t][v], g[t], A.kd, modulus, dq, dx, e0);
-                            dx0[t][v] += dx;
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) {
+                                Cplx dq, dx;
+                                pair_bwd_cmod(Cplx{q0[v], q1[v]}, Cplx{x0[t][v], x1[t][v]}, g[t], dq, dx);
+                                dx0[t][v] += dx.re;
+                                dx1[t][v] += dx.im;
+                            } else {
+                                float dq, dx, e0 = 0.f;
+                                pair_bwd_real<MODEL, HEAD>(q0[v], x0[t][v], g[t], A.kd, modulus, dq, dx, e0);
+                                dx0[t][v] += dx;
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (__builtin_popcount(m) >= kDense) positions(std::true_type{});
+            else positions(std::false_type{});
         }
     }
+    MKB_TRACE_T(tr_t2);
     // dx of this (position tile, row slice) goes straight into the table gradient: x_slices (8) fp32 atomics per
     // element of a used pool row (~5 M per step, spread over the kernel), instead of a [slices, P, De] partial buffer
     // plus a reduction kernel.  Tiles nobody uses (n_rows == 0) write nothing.
@@ -530,12 +604,36 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_x_kernel(PoolArgs A) {
                 const float sgn = (CP && KPT % 2 == 0) ? -1.f : 1.f;  // the packed path accumulated -dx
 #pragma unroll
                 for (int v = 0; v < KPT; ++v) {
+#if defined(MKB_EXP_NO_FLUSH)
+                    if (A.P < 0) atomicAdd(row + u0 + v, sgn * dx0[t][v] + dx1[t][v]);
+#elif defined(MKB_EXP_WG_ATOMICS)
+                    __hip_atomic_fetch_add(row + u0 + v, sgn * dx0[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (CP) __hip_atomic_fetch_add(row + A.d + u0 + v, sgn * dx1[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
                     atomicAdd(row + u0 + v, sgn * dx0[t][v]);
                     if constexpr (CP) atomicAdd(row + A.d + u0 + v, sgn * dx1[t][v]);
+#endif
                 }
             }
         }
     }
+    MKB_TRACE_OUT(A, 2, tr_t0, tr_t1, tr_t2, n_rows);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: one launch
+// The dq pass and the dx pass read the same inputs and write disjoint outputs, so they are one grid.  One launch instead
+// of two saves a kernel boundary (~15 us between two large kernels on this part) and keeps two workgroups resident on
+// every CU for the whole launch.  Dispatch order (a CU issues oldest-first, so the order is the schedule): the first
+// q_first dq workgroups (one per CU), then the dx pass (fringe, heavy, light tiles: the heavy ones take the CUs' second
+// slots), then the remaining dq workgroups, which replace the first ones as they retire.  x_blocks == 0 or no dq blocks
+// runs one pass alone (A/B measurements).
+template <int MODEL, bool HEAD, int KPT, int NW>
+__global__ __launch_bounds__(NW * 64) void pool_bwd_kernel(PoolArgs A) {
+    extern __shared__ __attribute__((aligned(16))) int lds_bwd[];
+    const int b = (int)blockIdx.x;
+    if (b < A.q_first) pool_bwd_q_body<MODEL, HEAD, KPT, NW>(A, b, lds_bwd);
+    else if (b < A.q_first + A.x_blocks) pool_bwd_x_body<MODEL, HEAD, KPT, NW>(A, b - A.q_first, lds_bwd);
+    else pool_bwd_q_body<MODEL, HEAD, KPT, NW>(A, b - A.x_blocks, lds_bwd);
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
@@ -547,7 +645,7 @@ struct PoolLaunch {
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
-typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd_q, 2 bwd_x*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone*/, bool head, const PoolLaunch &L, const PoolArgs &A,
                               hipStream_t st);
 int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
 int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
@@ -561,13 +659,18 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
     if (which == 0) {
         dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.fwd_slices);
         hipLaunchKernelGGL((pool_fwd_kernel<MODEL, HEAD, KPT, NW>), grid, block, (size_t)3 * ((A.P + L.fwd_slices - 1) / L.fwd_slices) * 4, st, A);
-    } else if (which == 1) {
-        dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.q_slices);
-        hipLaunchKernelGGL((pool_bwd_q_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((size_t)(TI + 2) * ((A.P + L.q_slices - 1) / L.q_slices) + 32) * 4, st, A);
     } else {
-        dim3 grid((unsigned)(((A.P + TI - 1) / TI) * L.x_slices));
+        // which: 1 = both passes in one grid, 2 = dx pass only, 3 = dq pass only
         const size_t rows_per = (size_t)((A.B + L.x_slices - 1) / L.x_slices);
-        hipLaunchKernelGGL((pool_bwd_x_kernel<MODEL, HEAD, KPT, NW>), grid, block, ((TI + 2) * rows_per + 16) * 4, st, A);
+        const size_t lds_x = ((TI + 2) * rows_per + 16) * 4;
+        const size_t lds_q = ((size_t)(TI + 2) * ((A.P + L.q_slices - 1) / L.q_slices) + 32) * 4;
+        const unsigned xb = which == 3 ? 0u : (unsigned)(((A.P + TI - 1) / TI) * L.x_slices);
+        const unsigned qb = which == 2 ? 0u : (unsigned)(((A.B + TI - 1) / TI) * L.q_slices);
+        PoolArgs A2 = A;
+        A2.x_blocks = (int)xb;
+        A2.q_first = xb ? (int)(qb < 256u ? qb : (qb / 2 > 256u ? qb / 2 : 256u)) : 0;  // >= one dq workgroup per CU ahead of the dx pass
+        if (const char *e = getenv("MKB_POOL_QFIRST")) A2.q_first = xb ? (atoi(e) < (int)qb ? atoi(e) : (int)qb) : 0;
+        hipLaunchKernelGGL((pool_bwd_kernel<MODEL, HEAD, KPT, NW>), dim3(xb + qb), block, lds_x > lds_q ? lds_x : lds_q, st, A2);
     }
     MKB_LAUNCH_CHECK();
     return MKB_OK;

@@ -373,3 +373,34 @@ def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name,
         ref_loss = scoring.adversarial(pos_f.cpu(), neg_f.cpu(), w.cpu(), 1.0)
         np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=0, atol=1e-5)
     ns.check()
+
+
+@pytest.mark.parametrize("name,hidden", [("RotatE", 1500), ("RotatE", 3000), ("pRotatE", 1500), ("pRotatE", 3000),
+                                          ("TransE", 3000), ("TransE", 301), ("DistMult", 2600), ("RotatE", 257),
+                                          ("ComplEx", 700)])
+def test_every_launch_configuration_agrees_with_general_kernels(name, hidden, monkeypatch):
+    """The pooled kernels are instantiated per (units per lane, waves per workgroup); wide rows use 16-wave
+    workgroups whose register budget is tight (some instantiations spill to scratch).  Every configuration of the
+    launch table must give the general kernels' scores and gradients (MFMA route off so the tile kernels run)."""
+    from mkb_amd import losses
+    monkeypatch.setenv("MKB_POOL_NO_MFMA", "1")
+    ds, m, tb, ns, train = _setup("Umls", name, hidden, 40, 16)
+    idx = torch.as_tensor(np.random.RandomState(3).randint(len(train), size=40))
+    s, w = train[idx].cuda(), (torch.rand(40) + 0.1).cuda()
+    for mode in ("head-batch", "tail-batch"):
+        neg = ns.generate(s, mode)
+        plain = neg.clone()
+        got = {}
+        for tag, n in (("pooled", neg), ("general", plain)):
+            m.zero_grad(set_to_none=True)
+            sc = m(s, n, mode)
+            err = losses.Adversarial(alpha=0.5)(m(s), sc, w)
+            err.backward()
+            got[tag] = (sc.detach().cpu().numpy(), err.item(), m.entity_embedding.grad.cpu().numpy().copy(),
+                        m.relation_embedding.grad.cpu().numpy().copy())
+        scale = max(1.0, float(np.abs(got["general"][0]).max()))
+        np.testing.assert_allclose(got["pooled"][0], got["general"][0], rtol=0, atol=ATOL * scale)
+        np.testing.assert_allclose(got["pooled"][1], got["general"][1], rtol=0, atol=1e-5 * scale)
+        np.testing.assert_allclose(got["pooled"][2], got["general"][2], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got["pooled"][3], got["general"][3], rtol=1e-4, atol=1e-5)
+    ns.check()

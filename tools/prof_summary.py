@@ -28,5 +28,23 @@ def main(path):
         print(f"{k:112s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100 * a[1] / tot:6.2f}")
 
 
+def timeline(path, step_kernel="pool_draw_kernel", which=-3):
+    """One training step as a timeline: start offset, duration and the idle gap before every kernel."""
+    con = sqlite3.connect(path)
+    rows = con.execute("select name, start, end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if step_kernel in r[0]]
+    lo, hi = marks[which], marks[which + 1]
+    t0, prev_end, busy = rows[lo][1], rows[lo][1], 0
+    print(f"{'kernel':70s} {'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s}")
+    for name, s, e in rows[lo:hi]:
+        print(f"{short(name)[:70]:70s} {(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(s - prev_end) / 1e3:7.1f}")
+        busy += e - s
+        prev_end = e
+    print(f"step {(rows[hi][1] - t0) / 1e3:.1f} us, kernels busy {busy / 1e3:.1f} us, {hi - lo} launches")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "timeline":
+        timeline(sys.argv[1])
+    else:
+        main(sys.argv[1])

@@ -5,11 +5,12 @@
 #include <vector>
 
 struct C { float re, im; };
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int V>
 __global__ __launch_bounds__(1024) void k(float *out, const float *in, int iters, unsigned mask) {
-    float q0[8], q1[8], a0[8], a1[8];
-    for (int r = 0; r < 8; ++r) { q0[r] = in[threadIdx.x + r]; q1[r] = in[threadIdx.x + 8 + r]; a0[r] = 0; a1[r] = 0; }
+    float q0[8], q1[8], a0[8], a1[8], p0[8], p1[8];
+    for (int r = 0; r < 8; ++r) { q0[r] = in[threadIdx.x + r]; q1[r] = in[threadIdx.x + 8 + r]; a0[r] = 0; a1[r] = 0; p0[r] = 0; p1[r] = 0; }
     float x0 = in[threadIdx.x + 100], x1 = in[threadIdx.x + 101];
     float g[8];
     for (int r = 0; r < 8; ++r) g[r] = in[r + 200];
@@ -52,6 +53,31 @@ __global__ __launch_bounds__(1024) void k(float *out, const float *in, int iters
         } else if constexpr (V == 5) {  // rsq only: 8 per iteration
 #pragma unroll
             for (int r = 0; r < 8; ++r) a0[r] = __builtin_amdgcn_rsqf(a0[r] + x0);
+        } else if constexpr (V == 7) {  // backward body as shipped: two units per lane, packed math (8 pk + 2 rsq per row)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                f2 a = f2{q0[r], q1[r]} - f2{x0, x1}, b = f2{q1[r], q0[r]} - f2{x1, x0};
+                f2 n2 = a * a + b * b + f2{1e-30f, 1e-30f};
+                f2 w = f2{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)} * g[r];
+                f2 c0 = f2{a0[r], a1[r]} - w * a, c1 = f2{p0[r], p1[r]} - w * b;
+                a0[r] = c0.x; a1[r] = c0.y; p0[r] = c1.x; p1[r] = c1.y;
+            }
+        } else if constexpr (V == 8) {  // forward body as shipped: two units per lane (5 pk + 2 sqrt per row)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                f2 a = f2{q0[r], q1[r]} - f2{x0, x1}, b = f2{q1[r], q0[r]} - f2{x1, x0};
+                f2 n2 = a * a + b * b;
+                f2 c0 = f2{a0[r], a1[r]} + f2{__builtin_amdgcn_sqrtf(n2.x), __builtin_amdgcn_sqrtf(n2.y)};
+                a0[r] = c0.x; a1[r] = c0.y;
+            }
+        } else if constexpr (V == 9) {  // packed fma peak reference: 4 pk_fma per row
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                f2 c = f2{a0[r], a1[r]}, d = f2{p0[r], p1[r]};
+                c = c * f2{x0, x1} + f2{q0[r], q1[r]}; d = d * f2{x1, x0} + f2{q1[r], q0[r]};
+                c = c * f2{x1, x0} + f2{q1[r], q0[r]}; d = d * f2{x0, x1} + f2{q0[r], q1[r]};
+                a0[r] = c.x; a1[r] = c.y; p0[r] = d.x; p1[r] = d.y;
+            }
         } else if constexpr (V == 6) {  // backward body without rsq (mul instead) - isolates the transcendental
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -61,7 +87,7 @@ __global__ __launch_bounds__(1024) void k(float *out, const float *in, int iters
             }
         }
     }
-    for (int r = 0; r < 8; ++r) s += a0[r] + a1[r];
+    for (int r = 0; r < 8; ++r) s += a0[r] + a1[r] + p0[r] + p1[r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -101,6 +127,13 @@ int main() {
         run<4>("4 fma per row (peak reference)", blocks, thr, it, 0);
         run<5>("1 rsq per row", blocks, thr, it, 0);
         run<6>("bwd body without rsq", blocks, thr, it, 0);
+    }
+    for (int wps : {1, 2, 4}) {
+        printf("-- packed bodies (two units per lane), %d waves / SIMD\n", wps);
+        run<7>("bwd body packed (8 pk + 2 rsq)", 128 * wps, 512, it, 0);
+        run<8>("fwd body packed (5 pk + 2 sqrt)", 128 * wps, 512, it, 0);
+        run<9>("4 pk_fma per row (packed peak reference)", 128 * wps, 512, it, 0);
+        run<5>("1 rsq per row", 128 * wps, 512, it, 0);
     }
     run<1>("bwd straight, 8 waves/SIMD", 512, 1024, it, 0);
     run<1>("bwd straight, 2 waves/SIMD", 128, 1024, it, 0);
