@@ -245,6 +245,7 @@ def main():
         run_step(ctx, i)
     barrier()
     prof_kind = args.profile_kernel
+    merged_bwd = MODEL not in ("ComplEx", "DistMult")
     if prof_kind == "auto":
         for k in kinds:
             _hip.profile_enable(k, True)
@@ -257,6 +258,7 @@ def main():
             tot[k] = ms
             _hip.profile_enable(k, False)
         prof_kind = max(("pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam"), key=lambda k: tot[k])
+        merged_bwd = tot["pool_bwd_x"] == 0.0  # VALU models: the dq and dx passes are one launch, timed as pool_bwd_q
         if args.breakdown and rank == 0:
             print("probe ms/step by kernel class:", {k: round(v / 8, 4) for k, v in tot.items()}, file=sys.stderr)
     if prof_kind != "none":
@@ -267,12 +269,15 @@ def main():
     for i in range(args.steps):
         loss = run_step(ctx, args.warmup + 8 + i)
     ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work
+    t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    if args.breakdown and rank == 0:
+        print(f"host enqueue {t_host / args.steps * 1e3:.4f} ms/step of {dt / args.steps * 1e3:.4f} ms/step", file=sys.stderr)
     ctx["sampler"].check()
     assert torch.isfinite(loss).item()
     if world > 1:  # rows: replicas must hold identical tables; dims: every rank must have computed the same loss
@@ -308,10 +313,13 @@ def main():
         else:
             # logical gather/scatter bytes of the reference formulation, per pass over the negatives:
             # every scored slot reads its entity row (fwd) / re-reads it and adds one gradient row (bwd)
-            alg = Bk * K * De * 4
-            what = (f"{prof_kind} kernel: logical bytes of the reference formulation (B*K entity rows of {De * 4} B "
-                    f"gathered / re-read / scattered once by this pass); the kernel itself is VALU-bound and reuses "
-                    f"each pool row from registers, so the logical rate may exceed the HBM peak")
+            passes = 2 if (prof_kind == "pool_bwd_q" and merged_bwd) else 1
+            alg = passes * Bk * K * De * 4
+            label = "pool_bwd (dq + dx passes, one launch)" if passes == 2 else prof_kind
+            what = (f"{label} kernel: logical bytes of the reference formulation (B*K entity rows of {De * 4} B "
+                    f"gathered / re-read / scattered once per pass, {passes} pass(es) in this launch); the kernel itself is "
+                    f"VALU-bound (transcendental rate, DESIGN.md section 5) and reuses each pool row from registers, so "
+                    f"the logical rate may exceed the HBM peak")
         ach = alg / avg_s / 1e9
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/traffic.json)
         try:

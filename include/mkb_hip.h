@@ -99,7 +99,8 @@ int mkb_adversarial(const float *pos, const float *neg, const float *weight, con
  *   with numpy's legacy MT19937 randint + np.in1d(assume_unique=True, invert=True) of numpy >= 1.24:
  *   neg [B,K] int64 out; optional outs for the pooled scoring path: pool [2K] int64 (the shared candidate
  *   draw), pos [B,K] int32 (neg[i,j] == pool[pos[i,j]]), cnt [B,2K] uint16 (multiplicity of each pool
- *   position in row i).  status [1] int32 device out: 0 / MKB_ERR_KEY / MKB_ERR_EMPTY (first failing row
+ *   position in row i), touched [2K + 2B] int64 (the entity rows a training step on this batch reads: the pool,
+ *   then the batch's heads, then its tails -- the id list of mkb_adam_rows_catchup / _step).  status [1] int32 device out: 0 / MKB_ERR_KEY / MKB_ERR_EMPTY (first failing row
  *   in status[1]); checked lazily by the host with mkb_sampler_status.
  */
 typedef struct mkb_sampler mkb_sampler_t;
@@ -108,7 +109,7 @@ int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t n_relation
                        const int64_t *head_values_host, const int64_t *tail_keys_host, int64_t n_tail_keys,
                        const int64_t *tail_offsets_host, const int64_t *tail_values_host, void *stream);
 int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int64_t B, int mode, int64_t *neg,
-                         int64_t *pool, int32_t *pos, uint16_t *cnt, void *stream);
+                         int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream);
 int mkb_sampler_status(mkb_sampler_t *s, void *stream); /* synchronises `stream`; returns 0 or the error */
 int mkb_sampler_get_state(mkb_sampler_t *s, uint32_t *key624_host, int32_t *pos_host, void *stream);
 int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_host, int32_t pos, void *stream);
@@ -164,9 +165,15 @@ int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts, int64_t n_rows,
                           int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float beta1, float beta2,
                           float eps, void *stream);
+typedef struct {
+    float *param, *grad, *exp_avg, *exp_avg_sq; /* a small dense tensor (e.g. the relation table), 16-byte aligned */
+    int64_t n;                                  /* elements */
+    int64_t step;                               /* its own step count (>= 1) */
+} mkb_adam_dense_t;
+/* rider: null, or one dense tensor that takes its mkb_adam_step (with zero_grad) inside the same launch. */
 int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                        int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr, float beta1,
-                       float beta2, float eps, void *stream);
+                       float beta2, float eps, const mkb_adam_dense_t *rider, void *stream);
 
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the

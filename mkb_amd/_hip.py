@@ -36,6 +36,11 @@ class Grads(Structure):
     _fields_ = [("g_ent", c_void_p), ("g_rel", c_void_p), ("g_modulus", c_void_p)]
 
 
+class AdamDense(Structure):  # mkb_adam_dense_t: a small dense tensor stepped inside mkb_adam_rows_step's launch
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("n", c_int64), ("step", c_int64)]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -53,7 +58,7 @@ _SIGNATURES = {
     "mkb_sampler_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_uint32, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_sampler_generate": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_void_p]),
     "mkb_sampler_status": (c_int, [c_void_p, c_void_p]),
     "mkb_sampler_get_state": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "mkb_sampler_set_state": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
@@ -77,7 +82,7 @@ _SIGNATURES = {
     "mkb_adam_rows_catchup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                       c_int64, c_float, c_float, c_float, c_void_p]),
     "mkb_adam_rows_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                   c_int64, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+                                   c_int64, c_int64, c_float, c_float, c_float, c_float, POINTER(AdamDense), c_void_p]),
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),
     "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                          c_void_p]),

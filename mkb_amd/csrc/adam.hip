@@ -29,14 +29,14 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
     p = p + (neg_step * m) * __builtin_amdgcn_rcpf(denom);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, float w1, float b2, float w2, float neg_step,
-                                                   float sqrt_bc2, float eps, int zero_grad) {
+// dense Adam (+ zero_grad) over a grid-stride range; shared by adam_kernel and the extra workgroups of the row step
+__device__ __forceinline__ void adam_dense_range(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                 float *__restrict__ v, int64_t n, int64_t first, int64_t stride, float w1,
+                                                 float b2, float w2, float neg_step, float sqrt_bc2, float eps, int zero_grad) {
     const int64_t n4 = n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g);
     float4 *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (int64_t i = first; i < n4; i += stride) {
         float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
         adam_one(pp.x, gg.x, mm.x, vv.x, w1, b2, w2, neg_step, sqrt_bc2, eps);
         adam_one(pp.y, gg.y, mm.y, vv.y, w1, b2, w2, neg_step, sqrt_bc2, eps);
@@ -46,12 +46,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
         if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // tail (n not a multiple of 4)
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = (n4 << 2) + first; i < n; i += stride) {
         float pp = p[i], mm = m[i], vv = v[i];
         adam_one(pp, g[i], mm, vv, w1, b2, w2, neg_step, sqrt_bc2, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
         if (zero_grad) g[i] = 0.f;
     }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float w1, float b2, float w2, float neg_step,
+                                                   float sqrt_bc2, float eps, int zero_grad) {
+    adam_dense_range(p, g, m, v, n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, w1, b2, w2,
+                     neg_step, sqrt_bc2, eps, zero_grad);
 }
 
 }  // namespace mkb
@@ -102,6 +109,11 @@ struct AdamRowArgs {
     int64_t D;
     int32_t step;        // catch-up / flush: bring rows to `step`; step kernel: apply `step`
     float w1, b2, w2, eps, neg_step, sqrt_bc2;
+    // step kernel only: a small DENSE tensor (the relation table) stepped by extra workgroups of the same launch
+    int32_t n_ids;
+    float *dp, *dg, *dm, *dv;
+    int64_t dn;
+    float d_neg_step, d_sqrt_bc2;
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -150,6 +162,12 @@ __global__ __launch_bounds__(256) void adam_rows_catchup_kernel(AdamRowArgs A) {
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     __shared__ int s_old;
+    if ((int)blockIdx.x >= A.n_ids) {  // the dense rider: blocks [n_ids, gridDim.x)
+        const int64_t nb = (int64_t)gridDim.x - A.n_ids;
+        adam_dense_range(A.dp, A.dg, A.dm, A.dv, A.dn, ((int64_t)blockIdx.x - A.n_ids) * 256 + threadIdx.x, nb * 256, A.w1,
+                         A.b2, A.w2, A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
     const int64_t row = A.ids[blockIdx.x];
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
@@ -181,7 +199,7 @@ static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float 
 extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                                      int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto,
                                      float beta1, float beta2, float eps, void *stream) {
-    mkb::AdamRowArgs A;
+    mkb::AdamRowArgs A{};
     if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, 0.f, beta1, beta2, eps)) return rc;
     const int64_t n = ids ? n_ids : n_rows;
     if (n <= 0 || step_upto <= 0) return MKB_OK;
@@ -194,13 +212,25 @@ extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_av
 
 extern "C" int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                                   int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr,
-                                  float beta1, float beta2, float eps, void *stream) {
+                                  float beta1, float beta2, float eps, const mkb_adam_dense_t *rider, void *stream) {
     (void)n_rows;
-    mkb::AdamRowArgs A;
+    mkb::AdamRowArgs A{};
     if (int rc = mkb::fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, ids, D, step, lr, beta1, beta2, eps)) return rc;
     MKB_REQUIRE(grad && ids && step >= 1 && n_ids > 0 && n_ids <= INT32_MAX, "bad arguments");
+    A.n_ids = (int32_t)n_ids;
+    int64_t extra = 0;
+    if (rider && rider->n > 0) {
+        MKB_REQUIRE(rider->param && rider->grad && rider->exp_avg && rider->exp_avg_sq && rider->step >= 1, "bad dense rider");
+        MKB_REQUIRE((((uintptr_t)rider->param | (uintptr_t)rider->grad | (uintptr_t)rider->exp_avg | (uintptr_t)rider->exp_avg_sq) & 15) == 0,
+                    "buffers must be 16-byte aligned");
+        A.dp = rider->param; A.dg = rider->grad; A.dm = rider->exp_avg; A.dv = rider->exp_avg_sq; A.dn = rider->n;
+        A.d_neg_step = (float)(-((double)lr / (1.0 - pow((double)beta1, (double)rider->step))));
+        A.d_sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)rider->step));
+        extra = ((rider->n >> 2) + 255) / 256;
+        extra = extra < 1 ? 1 : (extra > 1024 ? 1024 : extra);
+    }
     mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(mkb::adam_rows_step_kernel, dim3((unsigned)n_ids), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(mkb::adam_rows_step_kernel, dim3((unsigned)(n_ids + extra)), dim3(256), 0, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

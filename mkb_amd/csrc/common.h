@@ -54,4 +54,26 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// loss.hip: Adversarial forward + gradient seeds.  defer_finish: the caller sums scratch[1 .. B] itself with
+// adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).
+int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
+                       float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
+                       hipStream_t st, bool defer_finish);
+
+#ifdef __HIPCC__
+// loss = -sum_i rowpart[i] / (2 W) by ONE 256-lane workgroup, fixed order (strided partial sums, wave64 butterfly, then
+// the four wave totals left to right): bit-reproducible.  red: 4 floats of LDS.
+__device__ __forceinline__ void adversarial_finish_block(const float *__restrict__ rowpart, int B, const float *__restrict__ scal,
+                                                         float *__restrict__ loss, float *red) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += rowpart[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = -0.5f * (red[0] + red[1] + red[2] + red[3]) / scal[0];
+}
+#endif
+
 }  // namespace mkb

@@ -7,9 +7,11 @@
 // Optional column multiplicities cnt[i,j] (pooled path: column = pool position used cnt times by row i):
 //   softmax and the sums run over columns weighted by cnt; dneg_ij is the summed gradient of its copies.
 //
-// Kernel 0 (single workgroup): W by a fixed reduction tree.  Kernel 1 (one wave per row, 4 rows per
-//   workgroup): row max / partition sum / weighted log-sigmoid sum with wave64 shuffle reductions, writes
-//   dpos, dneg and the per-row partial.  Kernel 2 (single workgroup): fixed-tree sum of the partials.
+// One launch up to 8192 rows: every workgroup (one wave per row, 4 rows) first reduces W itself with the fixed tree
+//   below (B / 256 loads per lane from L2; bit-identical in every workgroup), then row max / partition sum / weighted
+//   log-sigmoid sum with wave64 shuffle reductions, writes dpos, dneg and the per-row partial.  A second single-
+//   workgroup kernel sums the partials in a fixed order -- or, inside mkb_pool_step, the last workgroup of the row
+//   backward kernel does (adversarial_finish_block), so the fused step spends ONE launch on the loss.
 //   No float atomics: the loss is bit-reproducible run to run.
 #include "common.h"
 #include "model_math.h"
@@ -30,12 +32,16 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+__device__ __forceinline__ float weight_sum_block(const float *__restrict__ w, int B, float *red) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
+    return block_sum_256(acc, red);
+}
+
 // scal[0] = W
 __global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict__ w, int B, float *__restrict__ scal) {
     __shared__ float red[4];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
-    acc = block_sum_256(acc, red);
+    const float acc = weight_sum_block(w, B, red);
     if (threadIdx.x == 0) scal[0] = acc;
 }
 
@@ -43,8 +49,12 @@ __global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
                                                                int B, int K, float alpha, const float *__restrict__ scal,
-                                                               float *__restrict__ dpos, float *__restrict__ dneg,
-                                                               float *__restrict__ rowpart) {
+                                                               float *__restrict__ scal_out, float *__restrict__ dpos,
+                                                               float *__restrict__ dneg, float *__restrict__ rowpart) {
+    __shared__ float red[4];
+    // scal == nullptr: W is reduced here, by every workgroup alike; workgroup 0 publishes it for the finish step
+    const float W = scal ? scal[0] : weight_sum_block(w, B, red);
+    if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
@@ -67,7 +77,6 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
     }
     z = wave_sum(z);
     s = wave_sum(s);
-    const float W = scal[0];
     const float wi = w[i];
     const float coef = 0.5f * wi / W;
     const float invz = 1.f / z;
@@ -90,10 +99,26 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
 __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__restrict__ rowpart, int B,
                                                                  const float *__restrict__ scal, float *__restrict__ loss) {
     __shared__ float red[4];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < B; i += 256) acc += rowpart[i];
-    acc = block_sum_256(acc, red);
-    if (threadIdx.x == 0) loss[0] = -0.5f * acc / scal[0];
+    adversarial_finish_block(rowpart, B, scal, loss, red);
+}
+
+int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
+                       float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
+                       hipStream_t st, bool defer_finish) {
+    float *scal = scratch, *rowpart = scratch + 1;
+    const float *scal_in = weight_sum;  // W of the whole (sharded) batch when the caller supplies it
+    ProfScope ps(MKB_PROF_LOSS, st);
+    if (!weight_sum && B > 8192) {      // too many rows for every workgroup to re-reduce W: one extra launch
+        hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
+        scal_in = scal;
+    }
+    hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
+                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart);
+    if (!defer_finish)
+        hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B,
+                           weight_sum ? weight_sum : scal, loss);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
 }
 
 }  // namespace mkb
@@ -105,14 +130,6 @@ extern "C" int mkb_adversarial(const float *pos, const float *neg, const float *
                                float *dneg, float *scratch, void *stream) {
     MKB_REQUIRE(pos && neg && weight && loss && dpos && dneg && scratch, "null pointer");
     MKB_REQUIRE(B > 0 && K > 0 && B <= INT32_MAX && K <= INT32_MAX, "bad B / K");
-    hipStream_t st = (hipStream_t)stream;
-    float *scal = scratch, *rowpart = scratch + 1;
-    ProfScope ps(MKB_PROF_LOSS, st);
-    if (weight_sum) scal = const_cast<float *>(weight_sum);  // W of the whole (sharded) batch, supplied by the caller
-    else hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
-    hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                       (int)B, (int)K, alpha, scal, dpos, dneg, rowpart);
-    hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B, scal, loss);
-    MKB_LAUNCH_CHECK();
-    return MKB_OK;
+    return adversarial_launch(pos, neg, weight, cnt, B, K, alpha, weight_sum, loss, dpos, dneg, scratch, (hipStream_t)stream,
+                              /*defer_finish=*/false);
 }

@@ -223,9 +223,12 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
                                                           const int32_t *__restrict__ sorted_val,
                                                           const int32_t *__restrict__ sorted_pos, int K, int P, int P2,
                                                           int rows_per_wg, int64_t *__restrict__ neg, int32_t *__restrict__ posmap,
-                                                          uint16_t *__restrict__ cnt, int32_t *__restrict__ status) {
+                                                          uint16_t *__restrict__ cnt, int64_t *__restrict__ touched,
+                                                          int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_i32[];
     int32_t *sval = lds_i32, *spos = lds_i32 + P2;
+    if (touched && blockIdx.x == 0)  // id list of the rows a training step reads: pool | heads | tails
+        for (int e = threadIdx.x; e < P; e += 256) touched[e] = pool[e];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int words = (P + 31) / 32;
     const int wslot = wave < rows_per_wg ? wave : 0;  // idle waves alias slot 0 but never touch it
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
     int nf = 0;
     if (valid) {
         const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
+        if (touched && lane == 0) { touched[P + i] = h; touched[P + B + i] = t; }
         const int64_t key = head_mode ? r * key_stride + t : h * key_stride + r;
         HEntry ent{-1, 0, 0, 0, 0};
         if (csr.nk > 0) {
@@ -483,7 +487,7 @@ extern "C" int mkb_sampler_status(mkb_sampler_t *s, void *stream) {
 }
 
 extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int64_t B, int mode, int64_t *neg,
-                                    int64_t *pool, int32_t *pos, uint16_t *cnt, void *stream) {
+                                    int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
     MKB_REQUIRE(s && sample && neg, "null pointer");
     MKB_REQUIRE(mode == MKB_MODE_HEAD || mode == MKB_MODE_TAIL, "generate needs head-batch or tail-batch");
     MKB_REQUIRE(B >= 0 && B <= INT32_MAX, "bad B");
@@ -503,7 +507,7 @@ extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int
     const size_t lds = sizeof(int32_t) * ((size_t)3 * P2 + (size_t)rw * ((size_t)2 * P + (P + 31) / 32));
     hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)((B + rw - 1) / rw)), dim3(256), lds, st, sample, (int)B,
                        head ? 1 : 0, stride, c, s->pool, s->lastflag, s->sorted_val, s->sorted_pos, (int)s->K, P, P2, rw,
-                       neg, pos, cnt, s->status);
+                       neg, pos, cnt, touched, s->status);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

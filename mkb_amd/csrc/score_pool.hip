@@ -90,6 +90,9 @@ struct RowStepArgs {
     int64_t De, Dr;
     int d, B, nslices;
     float kd, gamma;
+    // row_bwd inside mkb_pool_step: its last workgroup also finishes the loss (adversarial_finish_block), or nullptr
+    const float *loss_rowpart, *loss_scal;
+    float *loss_out;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -196,6 +199,8 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
         extra = block_sum_256_row(extra, red);
         if (threadIdx.x == 0) atomicAdd(A.g_modulus, -extra);
     }
+    if (A.loss_out && blockIdx.x == gridDim.x - 1)  // the per-row loss terms were written by an earlier kernel
+        adversarial_finish_block(A.loss_rowpart, A.B, A.loss_scal, A.loss_out, red);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -373,8 +378,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
         ProfScope ps(MKB_PROF_POOL_FWD, st);
         return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part);
     }
-    MKB_CHECK_HIP(hipMemsetAsync(S, 0, (size_t)B * P * 4, st));
-    PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
+    PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);  // (the kernel also zero-fills the entries no row uses)
     A.S = S;
     ProfScope ps(MKB_PROF_POOL_FWD, st);
     return launcher_of(tb->model)(0, head, L, A, st);
@@ -517,7 +521,11 @@ extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, 
     RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, nullptr, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
-    if (int rc = mkb_adversarial(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, stream)) return rc;
+    if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
+                                    /*defer_finish=*/true)) return rc;
+    ra.loss_rowpart = w.scratch + 1;
+    ra.loss_scal = weight_sum ? weight_sum : w.scratch;
+    ra.loss_out = loss;
     // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false)) return rc;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);

@@ -200,7 +200,11 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
 #pragma unroll
             for (int r = 0; r < TI; ++r) c[r] = (i0 + r < A.B) ? A.cnt[(int64_t)(i0 + r) * A.P + p] : 0;
 #pragma unroll
-            for (int r = 0; r < TI; ++r) m_own |= (c[r] != 0) ? (1u << r) : 0u;
+            for (int r = 0; r < TI; ++r) {
+                m_own |= (c[r] != 0) ? (1u << r) : 0u;
+                // entries no row uses are defined as 0 (the pair loop below never visits them): no memset launch
+                if (c[r] == 0 && i0 + r < A.B) A.S[(int64_t)(i0 + r) * A.P + p] = 0.f;
+            }
         }
         int tot;
         const int slot = n_act + wg_compact_slot<NW>(m_own != 0, s_wave_cnt, &tot);

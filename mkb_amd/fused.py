@@ -119,7 +119,7 @@ class FusedTrainStep:
         ent = m.entity_embedding
         lazy = getattr(ent, "_mkb_lazy", None)
         if lazy is not None:  # row-lazy Adam: the rows this step reads must be current before the forward pass
-            ids = torch.cat([info.pool, sample[:, 0], sample[:, 2]])
+            ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
             lazy.catch_up(ent, ids)
             ent._mkb_touched = ids
         with torch.cuda.device(dev):

@@ -236,7 +236,7 @@ class DimShardedStep:
         ent = m.entity_embedding
         lazy = getattr(ent, "_mkb_lazy", None)
         if lazy is not None:
-            ids = torch.cat([info.pool, sample[:, 0], sample[:, 2]])
+            ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
             lazy.catch_up(ent, ids)
             ent._mkb_touched = ids
         lib, tb = _hip.lib(), m._tables()

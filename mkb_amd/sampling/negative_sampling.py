@@ -71,6 +71,7 @@ class PoolInfo:
     def __init__(self, pool, pos, cnt, size, mode_id, sample):
         self.pool, self.pos, self.cnt, self.size, self.mode_id = pool, pos, cnt, size, mode_id
         self.sample_ptr, self.batch = sample.data_ptr(), sample.shape[0]
+        self.touched = None  # [2K + 2B] entity rows a step on this batch reads: pool | heads | tails
 
     def usable_for(self, model, sample, mode_id):
         return (self.enabled and mode_id == self.mode_id and sample.shape[0] == self.batch
@@ -131,15 +132,17 @@ class NegativeSampling:
         pool = torch.empty(2 * K, dtype=torch.int64, device=dev)
         pos = torch.empty((B, K), dtype=torch.int32, device=dev)
         cnt = torch.empty((B, 2 * K), dtype=torch.uint16, device=dev)
+        touched = torch.empty(2 * K + 2 * B, dtype=torch.int64, device=dev)  # pool | heads | tails (row-lazy Adam)
         mode_id = _hip.mode_id(mode)
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_sampler_generate(self._handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg),
-                                                       _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt),
+                                                       _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt), _hip.ptr(touched),
                                                        _hip.stream_ptr()), "mkb_sampler_generate")
         if origin != dev:
             self.check()
             return neg.to(origin)
         neg._mkb_pool = PoolInfo(pool, pos, cnt, K, mode_id, sample)
+        neg._mkb_pool.touched = touched
         return neg
 
     def check(self):
