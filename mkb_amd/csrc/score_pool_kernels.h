@@ -263,9 +263,11 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
                     part[r] = 0.f;
                     if (DENSE || (m & (1u << r))) {  // out-of-range units hold q = x = 0 and contribute exactly 0
                         if constexpr (CP && KPT % 2 == 0) {
-                            f2 acc = f2{0.f, 0.f};
+                            // (start from the first term: 0 + t is a real v_pk_add, -0 semantics forbid folding it)
+                            f2 acc = pair_term_cmod2(f2{q0[r][0], q0[r][1]}, f2{q1[r][0], q1[r][1]}, f2{x0[0], x0[1]},
+                                                     f2{x1[0], x1[1]});
 #pragma unroll
-                            for (int v = 0; v < KPT; v += 2)
+                            for (int v = 2; v < KPT; v += 2)
                                 acc += pair_term_cmod2(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
                                                        f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]});
                             part[r] = acc.x + acc.y;
