@@ -155,3 +155,56 @@ def test_row_lazy_adam_is_bitwise_dense_adam():
     ol.flush()
     assert torch.equal(pl.data, pd.data)
     assert torch.equal(ol.state[pl]["m"], od.state[pd]["m"]) and torch.equal(ol.state[pl]["v"], od.state[pd]["v"])
+
+
+def test_sampler_emits_touched_rows_and_adam_rider_equals_separate_launches():
+    """mkb_sampler_generate's `touched` list is pool | heads | tails of the batch, and a relation table that rides
+    the row-lazy Adam launch (mkb_adam_dense_t) ends bit-identical to one stepped by its own mkb_adam_step launch."""
+    from mkb_amd import datasets, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=3)
+    s = train[:64].contiguous()
+    neg = ns.generate(s, "tail-batch")
+    info = neg._mkb_pool
+    want = torch.cat([info.pool, s[:, 0], s[:, 2]])
+    assert torch.equal(info.touched, want)
+
+    results = []
+    for ride in (True, False):
+        g = torch.Generator(device="cpu").manual_seed(5)
+        ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())   # >= 4096 rows: steps row-lazily
+        rel = torch.nn.Parameter(torch.randn(37, 64, generator=g).cuda())
+        opt = optim.Adam([ent, rel], lr=1e-2, lazy_rows=True)
+        if not ride:
+            opt._rider = lambda: (None, None)
+        for it in range(5):
+            ids = torch.randperm(5000, generator=g)[:300].cuda()  # distinct: index_put with duplicates is order-dependent
+            ent.grad = torch.zeros_like(ent)
+            ent.grad[ids] = torch.randn(300, 64, generator=g).cuda()
+            rel.grad = torch.randn(37, 64, generator=g).cuda()
+            opt.catch_up(ent, ids)
+            ent._mkb_touched = ids
+            opt.step()
+            opt.zero_grad()
+            assert rel.grad.abs().max().item() == 0.0  # zero_grad is fused into both routes
+        opt.flush()
+        torch.cuda.synchronize()
+        results.append((ent.detach().cpu().numpy().copy(), rel.detach().cpu().numpy().copy()))
+    assert np.array_equal(results[0][0], results[1][0])
+    assert np.array_equal(results[0][1], results[1][1])
+    # and both equal torch.optim.Adam on the same gradients to a few ulp of the update
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())
+    rel = torch.nn.Parameter(torch.randn(37, 64, generator=g).cuda())
+    ref = torch.optim.Adam([ent, rel], lr=1e-2)
+    for it in range(5):
+        ids = torch.randperm(5000, generator=g)[:300].cuda()  # distinct: index_put with duplicates is order-dependent
+        ent.grad = torch.zeros_like(ent)
+        ent.grad[ids] = torch.randn(300, 64, generator=g).cuda()
+        rel.grad = torch.randn(37, 64, generator=g).cuda()
+        ref.step()
+    np.testing.assert_allclose(results[0][0], ent.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(results[0][1], rel.detach().cpu().numpy(), rtol=0, atol=2e-6)
