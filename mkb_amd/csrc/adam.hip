@@ -128,29 +128,45 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
     p = p + (neg_step * m) * __builtin_amdgcn_rcpf(denom);
 }
 
-// replay the zero-gradient steps (from, to] of one row; 256 lanes, float4 per lane, whole row in registers
+// replay the zero-gradient steps (from, to] of one row.  The replay is a serial chain per element (2 transcendentals
+// per step) and a row's gap can be hundreds of steps (entities only the random pool ever touches), so the kernel's
+// duration is its longest chain: kCatchThreads lanes x 2 elements keep that chain short (256 lanes x float4, two passes
+// per 2000-float row: 45 us at the headline shape; 1024 x float2: see DESIGN.md section 5).
+constexpr int kCatchThreads = 1024;
 __device__ __forceinline__ void replay_row(const AdamRowArgs &A, int64_t row, int from, int to) {
     float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
-    for (int64_t k = (int64_t)threadIdx.x * 4; k < A.D; k += 1024) {
-        const bool vec = k + 4 <= A.D;
-        float pp[4], mm[4], vv[4];
+    for (int64_t k = (int64_t)threadIdx.x * 2; k < A.D; k += 2 * kCatchThreads) {
+        const bool vec = k + 2 <= A.D;  // (rows are 8-byte aligned when D is even; an odd D ends on a single element)
+        float pp[2], mm[2], vv[2];
+        if (vec && (A.D & 1) == 0) {
+            const float2 a = *reinterpret_cast<const float2 *>(p + k), b = *reinterpret_cast<const float2 *>(m + k),
+                         c = *reinterpret_cast<const float2 *>(v + k);
+            pp[0] = a.x; pp[1] = a.y; mm[0] = b.x; mm[1] = b.y; vv[0] = c.x; vv[1] = c.y;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = vec || k + e < A.D;
-            pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+            for (int e = 0; e < 2; ++e) {
+                const bool ok = k + e < A.D;
+                pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+            }
         }
         for (int s = from + 1; s <= to; ++s) {
             const float2 c = A.consts[s];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
+            for (int e = 0; e < 2; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
         }
+        if (vec && (A.D & 1) == 0) {
+            *reinterpret_cast<float2 *>(p + k) = make_float2(pp[0], pp[1]);
+            *reinterpret_cast<float2 *>(m + k) = make_float2(mm[0], mm[1]);
+            *reinterpret_cast<float2 *>(v + k) = make_float2(vv[0], vv[1]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (vec || k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
+            for (int e = 0; e < 2; ++e)
+                if (k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void adam_rows_catchup_kernel(AdamRowArgs A) {
+__global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
     __shared__ int s_old;
     const int64_t row = A.ids ? A.ids[blockIdx.x] : (int64_t)blockIdx.x;
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
@@ -174,6 +190,19 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     __syncthreads();
     if (s_old == A.step) return;  // duplicate id: another workgroup owns this row
     float *p = A.p + row * A.D, *g = A.g + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
+    if ((A.D & 3) == 0) {  // 16-byte aligned rows: one float4 per lane and array
+        float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g);
+        float4 *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
+        for (int64_t k = threadIdx.x; k < (A.D >> 2); k += 256) {
+            float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+            adam_one(pp.x, gg.x, mm.x, vv.x, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
+            adam_one(pp.y, gg.y, mm.y, vv.y, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
+            adam_one(pp.z, gg.z, mm.z, vv.z, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
+            adam_one(pp.w, gg.w, mm.w, vv.w, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
+            p4[k] = pp; m4[k] = mm; v4[k] = vv; g4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     for (int64_t k = threadIdx.x; k < A.D; k += 256) {
         float pp = p[k], mm = m[k], vv = v[k];
         adam_one(pp, g[k], mm, vv, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
@@ -205,7 +234,7 @@ extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_av
     if (n <= 0 || step_upto <= 0) return MKB_OK;
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
     mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)n), dim3(mkb::kCatchThreads), 0, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
