@@ -20,5 +20,8 @@ for path in sys.argv[1:]:
     print(f"# {path}")
     print(f"{'kernel':72s} {'counter':12s} {'calls':>6s} {'mean_MB':>10s} {'x2_MB':>10s}")
     for (k, c), (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        mb = tot / n * 1024 / 1e6
-        print(f"{k:72s} {c:12s} {n:6d} {mb:10.3f} {2 * mb if c == 'FETCH_SIZE' else float('nan'):10.3f}")
+        if c.endswith("_SIZE"):
+            mb = tot / n * 1024 / 1e6
+            print(f"{k:72s} {c:12s} {n:6d} {mb:10.3f} {2 * mb if c == 'FETCH_SIZE' else float('nan'):10.3f}")
+        else:  # plain event counters (SQ_*): mean count per dispatch
+            print(f"{k:72s} {c:22s} {n:6d} {tot / n:16.0f}")
