@@ -189,6 +189,17 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
 
+    // the tile's query rows: issued first so that their latency overlaps the list build below
+    float q0[TI][KPT], q1[TI][KPT];
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+        if (i0 + r >= A.B) {
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+        }
+    }
+
     // positions used by at least one row of the tile, compacted into LDS
     MKB_TRACE_T(tr_t0);
     int n_act = 0;
@@ -215,16 +226,6 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
         }
         n_act += tot;
         __syncthreads();
-    }
-
-    float q0[TI][KPT], q1[TI][KPT];
-#pragma unroll
-    for (int r = 0; r < TI; ++r) {
-        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
-        if (i0 + r >= A.B) {
-#pragma unroll
-            for (int v = 0; v < KPT; ++v) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
-        }
     }
 
     MKB_TRACE_T(tr_t1);
@@ -333,6 +334,18 @@ __device__ __forceinline__ void pool_bwd_q_body(const PoolArgs &A, const int blo
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
 
+    // the tile's query rows first: their latency overlaps the list build
+    float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            if (i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+            dq0[r][v] = 0.f;
+            dq1[r][v] = 0.f;
+        }
+    }
     MKB_TRACE_T(tr_t0);
     int n_act = 0;
     for (int base = 0; base < Pn; base += WG) {
@@ -367,17 +380,6 @@ __device__ __forceinline__ void pool_bwd_q_body(const PoolArgs &A, const int blo
         __syncthreads();
     }
 
-    float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
-#pragma unroll
-    for (int r = 0; r < TI; ++r) {
-        load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
-#pragma unroll
-        for (int v = 0; v < KPT; ++v) {
-            if (i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
-            dq0[r][v] = 0.f;
-            dq1[r][v] = 0.f;
-        }
-    }
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
     float extra = 0.f;
 
@@ -493,6 +495,19 @@ __device__ __forceinline__ void pool_bwd_x_body(const PoolArgs &A, const int blo
     int *s_i = lds_dyn + TI * rows_per;                                   // batch rows of the slice that use the tile
     unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + (TI + 1) * rows_per);  // bit t: row uses position p0 + t
     int *s_wave_cnt = lds_dyn + (TI + 2) * rows_per;
+    // the tile's candidate rows first: their latency overlaps the row-list build
+    float x0[TI][KPT], x1[TI][KPT], dx0[TI][KPT], dx1[TI][KPT];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+        const bool pin = p0 + t < A.P;
+        load_units<CP, KPT>(A.ent + (pin ? A.pool[p0 + t] : 0) * A.De, A.d, NU, u0, x0[t], x1[t]);
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            if (!pin) { x0[t][v] = 0.f; x1[t][v] = 0.f; }
+            dx0[t][v] = 0.f;
+            dx1[t][v] = 0.f;
+        }
+    }
     MKB_TRACE_T(tr_t0);
 
     int n_rows = 0;
@@ -525,18 +540,6 @@ __device__ __forceinline__ void pool_bwd_x_body(const PoolArgs &A, const int blo
     }
 
     MKB_TRACE_T(tr_t1);
-    float x0[TI][KPT], x1[TI][KPT], dx0[TI][KPT], dx1[TI][KPT];
-#pragma unroll
-    for (int t = 0; t < TI; ++t) {
-        const bool pin = (p0 + t < A.P) && n_rows > 0;
-        load_units<CP, KPT>(A.ent + (pin ? A.pool[p0 + t] : 0) * A.De, A.d, NU, u0, x0[t], x1[t]);
-#pragma unroll
-        for (int v = 0; v < KPT; ++v) {
-            if (!pin) { x0[t][v] = 0.f; x1[t][v] = 0.f; }
-            dx0[t][v] = 0.f;
-            dx1[t][v] = 0.f;
-        }
-    }
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
 
     float qr0[kRing][KPT], qr1[kRing][KPT];
