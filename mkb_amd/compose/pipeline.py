@@ -12,6 +12,8 @@ README, or ``mkb_amd.optim.Adam``).
 """
 import collections
 
+import torch
+
 from ..fused import FusedTrainStep, pooled_supported
 from ..losses import Adversarial
 from ..models.base import BaseModel
@@ -43,6 +45,14 @@ class Pipeline:
                 and pooled_supported(model, dataset.batch_size, sampling.size)):
             fused = FusedTrainStep(model, loss.alpha)
 
+        pending = []  # fused path: losses stay on the device until the bar refreshes (one D2H copy per 10 steps)
+
+        def flush():
+            if pending:
+                for v in torch.stack(pending).tolist():
+                    self.metric_loss.update(v)
+                pending.clear()
+
         for epoch in range(self.epochs):
             bar = Bar(dataset=dataset, update_every=10)
             for data in bar:
@@ -63,8 +73,16 @@ class Pipeline:
                     error.backward()
                 _ = optimizer.step()
                 optimizer.zero_grad()
-                self.metric_loss.update(error.item())
+                if fused is not None:
+                    # the reference syncs on error.item() every step (pipeline.py:242); the rolling mean only has to be
+                    # current when it is shown, so the same values are fed to it in the same order, in batches
+                    pending.append(error.detach())
+                    if bar.due() or len(pending) >= 64:
+                        flush()
+                else:
+                    self.metric_loss.update(error.item())
                 bar.set_description(f"Epoch: {epoch}, loss: {self.metric_loss.get():4f}")
+            flush()
 
             if hasattr(sampling, "check"):
                 sampling.check()  # KeyError / empty-filter errors of this epoch's batches (lazy: no per-batch sync)

@@ -132,7 +132,10 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
 // per step) and a row's gap can be hundreds of steps (entities only the random pool ever touches), so the kernel's
 // duration is its longest chain: kCatchThreads lanes x 2 elements keep that chain short (256 lanes x float4, two passes
 // per 2000-float row: 45 us at the headline shape; 1024 x float2: see DESIGN.md section 5).
-constexpr int kCatchThreads = 1024;
+#ifndef MKB_CATCH_THREADS
+#define MKB_CATCH_THREADS 1024
+#endif
+constexpr int kCatchThreads = MKB_CATCH_THREADS;
 __device__ __forceinline__ void replay_row(const AdamRowArgs &A, int64_t row, int from, int to) {
     float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
     for (int64_t k = (int64_t)threadIdx.x * 2; k < A.D; k += 2 * kCatchThreads) {

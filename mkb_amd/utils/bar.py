@@ -14,6 +14,10 @@ class Bar:
     def __iter__(self):
         yield from self.bar
 
+    def due(self):
+        """True if the next ``set_description`` call will actually refresh the bar."""
+        return self.n % self.update_every == 0
+
     def set_description(self, text):
         if self.n % self.update_every == 0:
             self.bar.set_description(text)
