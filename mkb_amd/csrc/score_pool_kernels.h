@@ -633,7 +633,7 @@ __device__ __forceinline__ void pool_bwd_x_body(const PoolArgs &A, const int blo
 // The dq pass and the dx pass read the same inputs and write disjoint outputs, so they are one grid.  One launch instead
 // of two saves a kernel boundary (~15 us between two large kernels on this part) and keeps two workgroups resident on
 // every CU for the whole launch.  Dispatch order (a CU issues oldest-first, so the order is the schedule): the first
-// q_first dq workgroups (one per CU), then the dx pass (fringe, heavy, light tiles: the heavy ones take the CUs' second
+// q_first dq workgroups (on most CUs), then the dx pass (fringe, heavy, light tiles: the heavy ones take the CUs' second
 // slots), then the remaining dq workgroups, which replace the first ones as they retire.  x_blocks == 0 or no dq blocks
 // runs one pass alone (A/B measurements).
 template <int MODEL, bool HEAD, int KPT, int NW>
@@ -677,7 +677,9 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
         const unsigned qb = which == 2 ? 0u : (unsigned)(((A.B + TI - 1) / TI) * L.q_slices);
         PoolArgs A2 = A;
         A2.x_blocks = (int)xb;
-        A2.q_first = xb ? (int)(qb < 256u ? qb : (qb / 2 > 256u ? qb / 2 : 256u)) : 0;  // >= one dq workgroup per CU ahead of the dx pass
+        // dq workgroups ahead of the dx pass: a little under one per CU measured best (headline: 0 -> 169 us, 96..224 ->
+        // 160-165 us, 256 -> 170 us; the other shapes are flat within 2 %)
+        A2.q_first = xb ? (int)(qb < 160u ? qb : 160u) : 0;
         if (const char *e = getenv("MKB_POOL_QFIRST")) A2.q_first = xb ? (atoi(e) < (int)qb ? atoi(e) : (int)qb) : 0;
         hipLaunchKernelGGL((pool_bwd_kernel<MODEL, HEAD, KPT, NW>), dim3(xb + qb), block, lds_x > lds_q ? lds_x : lds_q, st, A2);
     }
