@@ -340,6 +340,17 @@ def main():
         roof = {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
                 "algorithmic_bytes_per_launch": alg, "note": what}
+        if MODEL == "RotatE" and prof_kind in ("pool_fwd", "pool_bwd_q", "pool_bwd_x"):
+            # the bound that actually binds: SIMD time of the packed pair bodies measured by
+            # tools/ubench/valu_chain.hip (profiles/r01_valu_ubench.txt) x the bodies this launch evaluates
+            info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
+            pairs = int((info.cnt.to(torch.int32) > 0).sum().item())  # (row, pool position) pairs actually evaluated
+            body_ns = 15.9 if prof_kind == "pool_fwd" else 19.6
+            n_pass = 2 if (prof_kind == "pool_bwd_q" and merged_bwd) else 1
+            floor_us = n_pass * pairs * (m_.hidden_dim / 128.0) / 1024.0 * body_ns * 1e-3
+            roof.update({"valu_floor_us": floor_us, "valu_frac": floor_us / (avg_s * 1e6),
+                         "valu_note": f"{n_pass} pass(es) x {pairs} (row, pool position) pairs x {m_.hidden_dim} complex dims "
+                                      f"/ 128 per wave-body / 1024 SIMDs x {body_ns} ns per body (micro-benchmark of the body alone)"})
     out = {
         "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
         else f"scored triples/sec (pos+K neg), {args.config}", "value": value, "unit": "triples/s",
