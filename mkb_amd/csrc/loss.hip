@@ -18,11 +18,6 @@
 
 namespace mkb {
 
-__device__ __forceinline__ float log_sigmoid(float z) {  // min(z,0) - log1p(exp(-|z|)), as ATen does
-    return fminf(z, 0.f) - log1pf(expf(-fabsf(z)));
-}
-__device__ __forceinline__ float sigmoid(float z) { return 1.f / (1.f + expf(-z)); }
-
 __device__ __forceinline__ float block_sum_256(float v, float *red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -45,7 +40,18 @@ __global__ __launch_bounds__(256) void weight_sum_kernel(const float *__restrict
     if (threadIdx.x == 0) scal[0] = acc;
 }
 
-// one wave per row; rowpart[i] = w_i * (ps_i + ns_i)
+// exp / log on the hardware transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp of the base-2 function): the arguments
+// here are scores of magnitude <= ~20, so exp's relative error stays ~1e-6 and log1p's absolute error ~1e-7 -- two
+// orders below the 1e-4 / 1e-5 parity tolerances -- at a tenth of the instructions of the correctly rounded libm forms.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fast_log_sigmoid(float z) {  // min(z,0) - log1p(exp(-|z|)), the form ATen uses
+    return fminf(z, 0.f) - 0.69314718055994531f * __builtin_amdgcn_logf(1.f + fast_exp(-fabsf(z)));
+}
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + fast_exp(-z)); }
+
+// one wave per row; rowpart[i] = w_i * (ps_i + ns_i).  Rows of up to 64 * kRowRegs columns are read ONCE into registers
+// (the three passes -- max, partition sums, gradient seeds -- then run on registers); longer rows re-read global memory.
+constexpr int kRowRegs = 16;
 __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
                                                                int B, int K, float alpha, const float *__restrict__ scal,
@@ -60,19 +66,48 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
     if (i >= B) return;
     const float *nrow = neg + (int64_t)i * K;
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
+    const bool in_regs = K <= 64 * kRowRegs;
+    float v[kRowRegs], c[kRowRegs];
+    if (in_regs) {
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < K;
+            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
+            v[t] = ok ? nrow[j] : 0.f;
+        }
+    }
     float m = -INFINITY;
-    for (int j = lane; j < K; j += 64)
-        if (!crow || crow[j]) m = fmaxf(m, alpha * nrow[j]);
+    if (in_regs) {
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t)
+            if (c[t] > 0.f) m = fmaxf(m, alpha * v[t]);
+    } else {
+        for (int j = lane; j < K; j += 64)
+            if (!crow || crow[j]) m = fmaxf(m, alpha * nrow[j]);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     float z = 0.f, s = 0.f;
-    for (int j = lane; j < K; j += 64) {
-        const float c = crow ? (float)crow[j] : 1.f;
-        if (c > 0.f) {
-            const float v = nrow[j];
-            const float e = c * expf(alpha * v - m);
-            z += e;
-            s += e * log_sigmoid(-v);
+    if (in_regs) {
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t) {
+            if (c[t] > 0.f) {
+                const float e = c[t] * fast_exp(alpha * v[t] - m);
+                z += e;
+                s += e * fast_log_sigmoid(-v[t]);
+                c[t] = e;  // keep the softmax numerator for the gradient pass
+            }
+        }
+    } else {
+        for (int j = lane; j < K; j += 64) {
+            const float cc = crow ? (float)crow[j] : 1.f;
+            if (cc > 0.f) {
+                const float vv = nrow[j];
+                const float e = cc * fast_exp(alpha * vv - m);
+                z += e;
+                s += e * fast_log_sigmoid(-vv);
+            }
         }
     }
     z = wave_sum(z);
@@ -80,19 +115,27 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
     const float wi = w[i];
     const float coef = 0.5f * wi / W;
     const float invz = 1.f / z;
-    for (int j = lane; j < K; j += 64) {
-        const float c = crow ? (float)crow[j] : 1.f;
-        float g = 0.f;
-        if (c > 0.f) {
-            const float v = nrow[j];
-            g = coef * (c * expf(alpha * v - m) * invz) * sigmoid(v);
+    if (in_regs) {
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t) {
+            const int j = lane + 64 * t;
+            if (j < K) dneg[(int64_t)i * K + j] = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
         }
-        dneg[(int64_t)i * K + j] = g;
+    } else {
+        for (int j = lane; j < K; j += 64) {
+            const float cc = crow ? (float)crow[j] : 1.f;
+            float g = 0.f;
+            if (cc > 0.f) {
+                const float vv = nrow[j];
+                g = coef * (cc * fast_exp(alpha * vv - m) * invz) * fast_sigmoid(vv);
+            }
+            dneg[(int64_t)i * K + j] = g;
+        }
     }
     if (lane == 0) {
         const float p = pos[i];
-        dpos[i] = -coef * sigmoid(-p);
-        rowpart[i] = wi * (log_sigmoid(p) + s * invz);
+        dpos[i] = -coef * fast_sigmoid(-p);
+        rowpart[i] = wi * (fast_log_sigmoid(p) + s * invz);
     }
 }
 
