@@ -110,8 +110,42 @@ class Evaluation:
                 metrics = self.compute_score(model=model, test_set=test_set, metrics=metrics, device=self.device)
         return {name: round(metric.get(), 4) for name, metric in metrics.items()}
 
+    def relation_ranks(self, model, dataset, chunk=4096):
+        """Filtered rank (1-based) of the true relation of every triple among all relations, on the device: what
+        ``compute_score`` does with the ``relation-batch`` stream (datasets/base.py:254-305: the other true relations of
+        (h, ., t) are replaced by the target relation and biased by -1), without the per-item host loop."""
+        dev = model.entity_embedding.device
+        n_ent, n_rel = model.n_entity, model.n_relation
+        keys = self._true_keys(dev, n_ent, n_rel)["tail-batch"]  # sorted (h * R + r) * N + t
+        triples = torch.as_tensor(np.asarray(dataset, dtype=np.int64).reshape(-1, 3), device=dev)
+        cand = torch.arange(n_rel, device=dev)
+        out = []
+        for lo in range(0, len(triples), chunk):
+            s = triples[lo: lo + chunk]
+            h, r, t = s[:, 0:1], s[:, 1:2], s[:, 2:3]
+            k = (h * n_rel + cand) * n_ent + t                       # [b, R] keys of (h, r', t)
+            pos = torch.searchsorted(keys, k.reshape(-1)).clamp_(max=keys.numel() - 1).view_as(k)
+            true = keys[pos] == k
+            rel = torch.where(true, r.expand_as(k), cand.expand_as(k))
+            bias = torch.where(true & (cand != r), -1.0, 0.0)
+            neg = torch.stack([h.expand_as(k), rel, t.expand_as(k)], dim=-1)  # [b, R, 3]
+            score = model(neg.contiguous()) + bias
+            target = score.gather(1, r)
+            out.append(1 + (score > target).sum(dim=1))
+        return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=dev)
+
     def eval_relations(self, model, dataset):
         metrics = collections.OrderedDict({m: Mean() for m in ["MRR", "MR", "HITS@1", "HITS@3", "HITS@10"]})
+        if self._device_ok(model) and not getattr(self, "force_reference_path", False) and len(dataset) > 0:
+            with torch.no_grad():
+                torch.empty((), dtype=torch.int64).random_()  # the reference's DataLoader iterator draws its base seed
+                for ranking in self.relation_ranks(model, dataset).tolist():
+                    metrics["MRR"].update(1.0 / ranking)
+                    metrics["MR"].update(ranking)
+                    metrics["HITS@1"].update(1.0 if ranking <= 1 else 0.0)
+                    metrics["HITS@3"].update(1.0 if ranking <= 3 else 0.0)
+                    metrics["HITS@10"].update(1.0 if ranking <= 10 else 0.0)
+            return {f"{name}_relations": round(metric.get(), 4) for name, metric in metrics.items()}
         with torch.no_grad():
             metrics = self.compute_score(model=model, test_set=self.get_relation_stream(dataset), metrics=metrics,
                                          device=self.device)

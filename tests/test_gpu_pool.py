@@ -231,9 +231,12 @@ def test_device_ranking_equals_reference_route(name):
                                device="cuda", num_workers=0)
     test = ds.test[:150]
     fast = ev.eval(model=m, dataset=test)
+    fast_rel = ev.eval_relations(model=m, dataset=test)
     ev.force_reference_path = True
     slow = ev.eval(model=m, dataset=test)
+    slow_rel = ev.eval_relations(model=m, dataset=test)
     assert fast == slow, (fast, slow)
+    assert fast_rel == slow_rel, (fast_rel, slow_rel)  # relation ranking: device searchsorted filter vs TestDatasetRelation
 
 
 @pytest.mark.parametrize("name,hidden,world", [("RotatE", 48, 2), ("ComplEx", 32, 4), ("TransE", 500, 2), ("pRotatE", 40, 2),
