@@ -296,7 +296,9 @@ def main():
         lo_, hi_ = probe.clone(), probe.clone()
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
-        assert lo_.item() == hi_.item(), "data-parallel replicas diverged"
+        # dims: the all-reduced scores (hence the loss) are bitwise equal on every rank with ring / tree all-reduce; allow
+        # for algorithms that are not (rel. 1e-5) instead of aborting the run.  rows: replicas apply identical updates.
+        assert abs(hi_.item() - lo_.item()) <= 1e-5 * max(1.0, abs(hi_.item())), "data-parallel replicas diverged"
 
     launches, kms = (0, 0.0)
     if prof_kind != "none":
