@@ -252,14 +252,21 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const int target = 256 * 16 / L.nw;  // workgroups for ~16 waves per CU
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    L.fwd_slices = clampi((256 * 16 / L.fnw + row_tiles - 1) / row_tiles, 1, kMaxSlices);
+    // Slice counts, swept on the headline shape and on the dimension shards of 2 / 4 / 8 GPUs (tools/shard_emulate.py:
+    // rows grow, rows get shorter, workgroups shrink to 4 / 2 / 1 waves).
+    // forward: ~32 waves per CU (short rows: 99 -> 79 us at the 8-GPU shard; flat at the headline shape)
+    L.fwd_slices = clampi((256 * 32 / L.fnw + row_tiles - 1) / row_tiles, 1, kMaxSlices);
     L.mfma = use_mfma(tb) ? 1 : 0;
-    // dq pass: it shares its launch with the dx pass, so half the waves suffice (headline: 2 slices instead of 4 keep the
-    // merged kernel at 160 us and save row_bwd 4 us of partial-buffer reads).  GEMM route: complete dQ rows.
-    L.q_slices = L.mfma ? 1 : clampi((target / 2 + row_tiles - 1) / row_tiles, 1, kMaxSlices);
-    // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU
+    // dq pass: it shares its launch with the dx pass, so with big workgroups half the waves suffice (headline: 2 slices
+    // instead of 4 keep the merged kernel at 160 us and save row_bwd 4 us of partial-buffer reads); 1- and 2-wave
+    // workgroups want the full count (8-GPU shard: 210 -> 185 us).  GEMM route: complete dQ rows.
+    const int q_target = L.nw >= 4 ? target / 2 : target;
+    L.q_slices = L.mfma ? 1 : clampi((q_target + row_tiles - 1) / row_tiles, 1, kMaxSlices);
+    // x pass: rows of a slice are listed in LDS (40 B each): keep a slice <= 256 rows so several workgroups fit a CU;
+    // single-wave workgroups do better with 256-row slices than with 128 (8-GPU shard: 209 -> 192 us)
     const int min_x = (int)((B + 255) / 256);
-    L.x_slices = clampi((target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
+    const int x_target = L.nw == 1 ? target / 2 : target;
+    L.x_slices = clampi((x_target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
     if (const char *e = getenv("MKB_POOL_FSLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd_slices = v; }
     if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma) L.q_slices = v; }
     if (const char *e = getenv("MKB_POOL_XSLICES")) { const int v = atoi(e); if (v >= min_x && v >= 1) L.x_slices = v; }
