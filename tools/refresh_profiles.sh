@@ -19,7 +19,7 @@ python tools/prof_summary.py $(ls $O/ktrace/*.db | head -1) timeline > $O/kernel
 python tools/pmc_summary.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) > $O/pmc_hbm_traffic.txt
 python tools/pmc_summary.py $(ls $O/pmc_sq/*.db | head -1) > $O/pmc_sq.txt 2>&1
 python bench.py --breakdown > $O/bench_default.json 2> $O/bench_default.err
-for c in wn18rr-rotate fb15k237-complex fb15k237-transe fb15k237-distmult umls-transe yago310-rotate; do
+for c in wn18rr-rotate fb15k237-complex fb15k237-transe fb15k237-distmult yago310-rotate; do
   python bench.py --config $c --no-cpu-baseline --mrr-epochs 0 2>/dev/null | tail -1 >> $O/bench_configs.jsonl
 done
 for n in 1 2 4 8; do echo "world=$n $(python tools/shard_emulate.py $n 2>/dev/null | tail -1)" >> $O/shard_emulate.txt; done
