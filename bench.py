@@ -81,7 +81,7 @@ def build(device, rank, world, seed=42, parallelism="dims"):
     # MKB_BENCH_DENSE_ADAM=1 selects the plain dense streaming kernel instead
     lazy = os.environ.get("MKB_BENCH_DENSE_ADAM", "0") != "1"
     opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
-                     lr=LR, lazy_rows=lazy)
+                     lr=LR, lazy_rows=lazy, draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None)
     step = parallel.DimShardedStep(model, ALPHA) if dims else FusedTrainStep(model, ALPHA)
     train = torch.as_tensor(train_np, device=device)
     weights = subsampling_weights(train_np).to(device)

@@ -163,9 +163,13 @@ int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
  *   mkb_adam_rows_step: apply step `step` with the real gradient to the rows in ids (duplicates allowed; they must
  *     be current through step-1) and clear their gradient rows.
  */
+/* draw_ahead: null, or a sampler whose NEXT pool draw (the single-workgroup MT19937 kernel every mkb_sampler_generate
+ * starts with) runs as one more workgroup of the catch-up launch (ids != null); the next mkb_sampler_generate on that
+ * sampler then only filters.  Same stream as the sampler's other calls; the negatives are bit-identical to drawing at
+ * generate time, and mkb_sampler_get_state keeps reporting the state before the pool drawn ahead. */
 int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts, int64_t n_rows,
                           int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float beta1, float beta2,
-                          float eps, void *stream);
+                          float eps, mkb_sampler_t *draw_ahead, void *stream);
 typedef struct {
     float *param, *grad, *exp_avg, *exp_avg_sq; /* a small dense tensor (e.g. the relation table), 16-byte aligned */
     int64_t n;                                  /* elements */

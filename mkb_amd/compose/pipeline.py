@@ -44,6 +44,8 @@ class Pipeline:
                 and type(loss) is Adversarial and model.entity_embedding.is_cuda
                 and pooled_supported(model, dataset.batch_size, sampling.size)):
             fused = FusedTrainStep(model, loss.alpha)
+            if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "draw_ahead", "x") is None:
+                optimizer.draw_ahead = sampling  # mkb_amd.optim.Adam: the next pool's draw rides the catch-up launch
 
         pending = []  # fused path: losses stay on the device until the bar refreshes (one D2H copy per 10 steps)
 

@@ -7,6 +7,7 @@
 // Pure HBM streaming: 4 reads + 3 writes (+1 write when zeroing g) of n floats; float4 per lane,
 // grid-stride over <= 2048 workgroups.
 #include "common.h"
+#include "sampler_draw.h"
 
 #include <math.h>
 
@@ -114,6 +115,9 @@ struct AdamRowArgs {
     float *dp, *dg, *dm, *dv;
     int64_t dn;
     float d_neg_step, d_sqrt_bc2;
+    // catch-up kernel only: block 0 draws the negative sampler's NEXT pool (pool_draw_body) when first_row_block is set
+    int32_t first_row_block;  // 1 with a draw block, else 0
+    DrawArgs draw;
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -171,7 +175,13 @@ __device__ __forceinline__ void replay_row(const AdamRowArgs &A, int64_t row, in
 
 __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
     __shared__ int s_old;
-    const int64_t row = A.ids ? A.ids[blockIdx.x] : (int64_t)blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_draw[];  // only sized when a draw block rides
+    if (A.first_row_block && blockIdx.x == 0) {  // dispatched first: ~8 us of serial work in the shadow of the row blocks
+        pool_draw_body<kCatchThreads>(A.draw, lds_draw);
+        return;
+    }
+    const int64_t bid = (int64_t)blockIdx.x - A.first_row_block;
+    const int64_t row = A.ids ? A.ids[bid] : bid;
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
     __syncthreads();
     const int old = s_old;
@@ -181,14 +191,15 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     __shared__ int s_old;
-    if ((int)blockIdx.x >= A.n_ids) {  // the dense rider: blocks [n_ids, gridDim.x)
+    const int bid = (int)blockIdx.x;
+    if (bid >= A.n_ids) {  // the dense rider: the last blocks
         const int64_t nb = (int64_t)gridDim.x - A.n_ids;
-        adam_dense_range(A.dp, A.dg, A.dm, A.dv, A.dn, ((int64_t)blockIdx.x - A.n_ids) * 256 + threadIdx.x, nb * 256, A.w1,
+        adam_dense_range(A.dp, A.dg, A.dm, A.dv, A.dn, ((int64_t)bid - A.n_ids) * 256 + threadIdx.x, nb * 256, A.w1,
                          A.b2, A.w2, A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
-    const int64_t row = A.ids[blockIdx.x];
+    if (bid == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
+    const int64_t row = A.ids[bid];
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
     __syncthreads();
     if (s_old == A.step) return;  // duplicate id: another workgroup owns this row
@@ -230,14 +241,17 @@ static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float 
 
 extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                                      int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto,
-                                     float beta1, float beta2, float eps, void *stream) {
+                                     float beta1, float beta2, float eps, mkb_sampler_t *draw_ahead, void *stream) {
     mkb::AdamRowArgs A{};
     if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, 0.f, beta1, beta2, eps)) return rc;
     const int64_t n = ids ? n_ids : n_rows;
     if (n <= 0 || step_upto <= 0) return MKB_OK;
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
+    size_t lds = 0;
+    if (draw_ahead && mkb::sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
     mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)n), dim3(mkb::kCatchThreads), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(n + A.first_row_block)), dim3(mkb::kCatchThreads), lds,
+                       (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

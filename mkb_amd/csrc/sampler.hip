@@ -21,13 +21,12 @@
 // No host round trip: errors (unseen key -> KeyError in the reference, empty filter -> infinite loop in the
 // reference) are recorded in a device status word that the host reads lazily.
 #include "common.h"
+#include "sampler_draw.h"
 
 #include <math.h>
 #include <vector>
 
 namespace mkb {
-
-constexpr int MT_N = 624, MT_M = 397;
 
 // One filter dictionary (negative_sampling.py:7-28) on the device: an open-addressing hash table whose entries
 // carry everything a row needs in ONE 32-byte load (no dependent key -> offsets -> flags chain), the concatenated
@@ -67,137 +66,16 @@ struct mkb_sampler {
     int64_t *pool;     // device [2K] (internal copy when the caller passes none)
     uint8_t *lastflag; // device [2K]
     int32_t *sorted_val, *sorted_pos;  // device [P2]: the pool sorted by (entity, position), P2 = pow2 >= 2K
+    uint32_t *mt_prev; // device [625]: generator state before a pool drawn ahead (sampler_draw_ahead)
+    bool drawn_ahead;  // the next generate's pool is already in pool / lastflag / sorted_*
     mkb::Csr head, tail;
 };
 
 namespace mkb {
 
-__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far) {
-    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
-    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
-}
-
-// exclusive prefix sum of a 0/1 flag over a 1024-thread block; returns rank, *total = block total
-__device__ __forceinline__ int block_scan_flag(bool flag, int *wave_tot, int *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long b = __ballot(flag);
-    const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) wave_tot[wave] = __popcll(b);
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const int c = wave_tot[w];
-        if (w < wave) base += c;
-        tot += c;
-    }
-    *total = tot;
-    return base + in_wave;
-}
-
-__global__ __launch_bounds__(1024) void pool_draw_kernel(uint32_t *__restrict__ mt_g, int32_t *__restrict__ pos_g,
-                                                         uint32_t rng, int P, int P2_arg, int64_t *__restrict__ pool,
-                                                         int64_t *__restrict__ pool2, uint8_t *__restrict__ lastflag,
-                                                         int32_t *__restrict__ sorted_val, int32_t *__restrict__ sorted_pos) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long skey[];  // [P2] sort keys, then...
-    uint32_t *pool_out_l = reinterpret_cast<uint32_t *>(skey + P2_arg);          // [P] drawn values
-    __shared__ uint32_t mt[MT_N];
-    __shared__ int wave_tot[16];
-    __shared__ int s_newpos;
-    const int tid = threadIdx.x;
-    if (tid < MT_N) mt[tid] = mt_g[tid];
-    int pos = pos_g[0];
-    uint32_t mask = rng;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    __syncthreads();
-    int have = 0;
-    if (rng == 0) {  // randint(1): no stream consumption
-        for (int p = tid; p < P; p += 1024) { pool[p] = 0; if (pool2) pool2[p] = 0; pool_out_l[p] = 0; }
-        have = P;
-    }
-    while (have < P) {
-        if (pos == MT_N) {  // regenerate the block: three parallel phases + the last word
-            uint32_t nv = 0;
-            if (tid < 227) nv = mt_twist(mt[tid], mt[tid + 1], mt[tid + MT_M]);
-            __syncthreads();
-            if (tid < 227) mt[tid] = nv;
-            __syncthreads();
-            if (tid >= 227 && tid < 454) nv = mt_twist(mt[tid], mt[tid + 1], mt[tid - 227]);
-            __syncthreads();
-            if (tid >= 227 && tid < 454) mt[tid] = nv;
-            __syncthreads();
-            if (tid >= 454 && tid < 623) nv = mt_twist(mt[tid], mt[tid + 1], mt[tid - 227]);
-            __syncthreads();
-            if (tid >= 454 && tid < 623) mt[tid] = nv;
-            __syncthreads();
-            if (tid == 623) mt[623] = mt_twist(mt[623], mt[0], mt[396]);
-            __syncthreads();
-            pos = 0;
-        }
-        const int avail = MT_N - pos;
-        uint32_t v = 0;
-        bool acc = false;
-        if (tid < avail) {
-            v = mt_temper(mt[pos + tid]) & mask;
-            acc = v <= rng;
-        }
-        int total;
-        const int rank = block_scan_flag(acc, wave_tot, &total);
-        const int need = P - have;
-        if (acc && rank < need) {
-            pool[have + rank] = (int64_t)v;
-            if (pool2) pool2[have + rank] = (int64_t)v;
-            pool_out_l[have + rank] = v;
-        }
-        if (tid == 0) s_newpos = MT_N;
-        __syncthreads();
-        if (acc && rank == need - 1) s_newpos = pos + tid + 1;  // word that produced the last needed draw
-        __syncthreads();
-        pos = s_newpos;
-        have += (total < need) ? total : need;
-        __syncthreads();
-    }
-    if (tid < MT_N) mt_g[tid] = mt[tid];
-    if (tid == 0) pos_g[0] = pos;
-    __syncthreads();
-    // ---- per-batch helpers for the row filter, all in LDS ------------------------------------------------
-    // keys[e] = entity << 13 | position, sorted ascending (bitonic): equal entities are adjacent, positions ascending
-    const int P2 = P2_arg;
-    for (int e = tid; e < P2; e += 1024)
-        skey[e] = e < P ? (((unsigned long long)(pool_out_l[e])) << 13) | (unsigned)e : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= P2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = tid; e < P2; e += 1024) {
-                const int partner = e ^ j;
-                if (partner > e) {
-                    const unsigned long long a = skey[e], b = skey[partner];
-                    const bool up = (e & k) == 0;
-                    if ((a > b) == up) { skey[e] = b; skey[partner] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int e = tid; e < P2; e += 1024) {
-        const unsigned long long kk = skey[e];
-        const bool real = kk != ~0ull;
-        sorted_val[e] = real ? (int32_t)(kk >> 13) : INT32_MAX;
-        sorted_pos[e] = real ? (int32_t)(kk & 8191u) : -1;
-        // lastflag[p]: no later position holds the same entity == next sorted key has a different entity
-        if (real) {
-            const unsigned long long nx = (e + 1 < P2) ? skey[e + 1] : ~0ull;
-            lastflag[kk & 8191u] = (nx == ~0ull || (nx >> 13) != (kk >> 13)) ? 1 : 0;
-        }
-    }
+__global__ __launch_bounds__(1024) void pool_draw_kernel(DrawArgs D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skey[];  // [P2] sort keys, then [P] drawn values
+    pool_draw_body<1024>(D, skey);
 }
 
 __device__ __forceinline__ uint32_t bloom_hash(int32_t v) { return (uint32_t)v * 2654435761u >> 7; }
@@ -224,11 +102,13 @@ __global__ __launch_bounds__(256) void filter_rows_kernel(const int64_t *__restr
                                                           const int32_t *__restrict__ sorted_pos, int K, int P, int P2,
                                                           int rows_per_wg, int64_t *__restrict__ neg, int32_t *__restrict__ posmap,
                                                           uint16_t *__restrict__ cnt, int64_t *__restrict__ touched,
-                                                          int32_t *__restrict__ status) {
+                                                          int64_t *__restrict__ pool_out, int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_i32[];
     int32_t *sval = lds_i32, *spos = lds_i32 + P2;
     if (touched && blockIdx.x == 0)  // id list of the rows a training step reads: pool | heads | tails
         for (int e = threadIdx.x; e < P; e += 256) touched[e] = pool[e];
+    if (pool_out && blockIdx.x == 0)  // the pool was drawn ahead of this call: hand the caller its copy
+        for (int e = threadIdx.x; e < P; e += 256) pool_out[e] = pool[e];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int words = (P + 31) / 32;
     const int wslot = wave < rows_per_wg ? wave : 0;  // idle waves alias slot 0 but never touch it
@@ -420,12 +300,14 @@ extern "C" int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t
     mkb_sampler *s = new mkb_sampler();
     s->n_entity = n_entity; s->n_relation = n_relation; s->K = K;
     s->mt = nullptr; s->mtpos = nullptr; s->status = nullptr; s->pool = nullptr; s->lastflag = nullptr;
+    s->mt_prev = nullptr; s->drawn_ahead = false;
     s->sorted_val = nullptr; s->sorted_pos = nullptr;
     int P2 = 2;
     while (P2 < 2 * K) P2 <<= 1;
     auto fail = [&](int rc) { mkb_sampler_destroy(s); return rc; };
     if (hipMalloc(&s->mt, sizeof(uint32_t) * MT_N) != hipSuccess || hipMalloc(&s->mtpos, sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&s->status, 2 * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&s->mt_prev, sizeof(uint32_t) * (MT_N + 1)) != hipSuccess ||
         hipMalloc(&s->pool, sizeof(int64_t) * (size_t)(2 * K)) != hipSuccess ||
         hipMalloc(&s->lastflag, (size_t)(2 * K)) != hipSuccess ||
         hipMalloc(&s->sorted_val, sizeof(int32_t) * (size_t)P2) != hipSuccess ||
@@ -447,7 +329,7 @@ extern "C" int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t
 extern "C" void mkb_sampler_destroy(mkb_sampler_t *s) {
     if (!s) return;
     (void)hipFree(s->mt); (void)hipFree(s->mtpos); (void)hipFree(s->status); (void)hipFree(s->pool); (void)hipFree(s->lastflag);
-    (void)hipFree(s->sorted_val); (void)hipFree(s->sorted_pos);
+    (void)hipFree(s->sorted_val); (void)hipFree(s->sorted_pos); (void)hipFree(s->mt_prev);
     free_csr(s->head);
     free_csr(s->tail);
     delete s;
@@ -456,6 +338,7 @@ extern "C" void mkb_sampler_destroy(mkb_sampler_t *s) {
 extern "C" int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_host, int32_t pos, void *stream) {
     MKB_REQUIRE(s && key624_host && pos >= 0 && pos <= MT_N, "bad state");
     hipStream_t st = (hipStream_t)stream;
+    s->drawn_ahead = false;  // a pool drawn ahead from the old state is discarded
     const int32_t zero[2] = {0, INT32_MAX};
     MKB_CHECK_HIP(hipMemcpyAsync(s->mt, key624_host, sizeof(uint32_t) * MT_N, hipMemcpyHostToDevice, st));
     MKB_CHECK_HIP(hipMemcpyAsync(s->mtpos, &pos, sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -467,6 +350,14 @@ extern "C" int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_ho
 extern "C" int mkb_sampler_get_state(mkb_sampler_t *s, uint32_t *key624_host, int32_t *pos_host, void *stream) {
     MKB_REQUIRE(s && key624_host && pos_host, "bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    if (s->drawn_ahead) {  // report the state the NEXT generate() logically starts from: before the pool drawn ahead
+        uint32_t p = 0;
+        MKB_CHECK_HIP(hipMemcpyAsync(key624_host, s->mt_prev, sizeof(uint32_t) * MT_N, hipMemcpyDeviceToHost, st));
+        MKB_CHECK_HIP(hipMemcpyAsync(&p, s->mt_prev + MT_N, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        MKB_CHECK_HIP(hipStreamSynchronize(st));
+        *pos_host = (int32_t)p;
+        return MKB_OK;
+    }
     MKB_CHECK_HIP(hipMemcpyAsync(key624_host, s->mt, sizeof(uint32_t) * MT_N, hipMemcpyDeviceToHost, st));
     MKB_CHECK_HIP(hipMemcpyAsync(pos_host, s->mtpos, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MKB_CHECK_HIP(hipStreamSynchronize(st));
@@ -486,6 +377,18 @@ extern "C" int mkb_sampler_status(mkb_sampler_t *s, void *stream) {
     return MKB_OK;
 }
 
+bool mkb::sampler_draw_ahead(mkb_sampler *s, mkb::DrawArgs *D, size_t *lds_bytes) {
+    if (!s || s->drawn_ahead) return false;
+    const int P = (int)(2 * s->K);
+    int P2 = 2;
+    while (P2 < P) P2 <<= 1;
+    *D = mkb::DrawArgs{s->mt, s->mtpos, s->mt_prev, (uint32_t)(s->n_entity - 1), P, P2, s->pool, nullptr, s->lastflag,
+                       s->sorted_val, s->sorted_pos};
+    *lds_bytes = mkb::draw_lds_bytes(P, P2);
+    s->drawn_ahead = true;
+    return true;
+}
+
 extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int64_t B, int mode, int64_t *neg,
                                     int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
     MKB_REQUIRE(s && sample && neg, "null pointer");
@@ -496,10 +399,18 @@ extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int
     int P2 = 2;
     while (P2 < P) P2 <<= 1;
     ProfScope ps(MKB_PROF_SAMPLER, st);
-    hipLaunchKernelGGL(pool_draw_kernel, dim3(1), dim3(1024), (size_t)P2 * 8 + (size_t)P * 4, st, s->mt, s->mtpos,
-                       (uint32_t)(s->n_entity - 1), P, P2, s->pool, pool, s->lastflag, s->sorted_val, s->sorted_pos);
+    const bool ahead = s->drawn_ahead;  // the pool was drawn inside an earlier launch (sampler_draw_ahead)
+    s->drawn_ahead = false;
+    if (!ahead) {
+        DrawArgs D{s->mt, s->mtpos, nullptr, (uint32_t)(s->n_entity - 1), P, P2, s->pool, pool, s->lastflag, s->sorted_val,
+                   s->sorted_pos};
+        hipLaunchKernelGGL(pool_draw_kernel, dim3(1), dim3(1024), draw_lds_bytes(P, P2), st, D);
+    }
     MKB_LAUNCH_CHECK();
-    if (B == 0) return MKB_OK;
+    if (B == 0) {
+        if (ahead && pool) MKB_CHECK_HIP(hipMemcpyAsync(pool, s->pool, sizeof(int64_t) * (size_t)P, hipMemcpyDeviceToDevice, st));
+        return MKB_OK;
+    }
     const bool head = mode == MKB_MODE_HEAD;
     const Csr &c = head ? s->head : s->tail;
     const int64_t stride = head ? s->n_entity : s->n_relation;
@@ -507,7 +418,7 @@ extern "C" int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int
     const size_t lds = sizeof(int32_t) * ((size_t)3 * P2 + (size_t)rw * ((size_t)2 * P + (P + 31) / 32));
     hipLaunchKernelGGL(filter_rows_kernel, dim3((unsigned)((B + rw - 1) / rw)), dim3(256), lds, st, sample, (int)B,
                        head ? 1 : 0, stride, c, s->pool, s->lastflag, s->sorted_val, s->sorted_pos, (int)s->K, P, P2, rw,
-                       neg, pos, cnt, touched, s->status);
+                       neg, pos, cnt, touched, ahead ? pool : nullptr, s->status);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

@@ -104,3 +104,38 @@ def test_empty_filter_raises_instead_of_hanging():
     ns.generate(torch.tensor([[0, 0, 1]]).cuda(), "tail-batch")  # true tails of (0,0) = {0,1} = every entity
     with pytest.raises(RuntimeError, match="whole candidate pool"):
         ns.check()
+
+
+def test_pool_drawn_ahead_inside_the_optimizer_launch_is_bit_identical():
+    """mkb_adam_rows_catchup(draw_ahead=sampler): the next pool is drawn by one more workgroup of the optimizer's
+    catch-up launch instead of the stand-alone kernel.  Negatives, pools and the reported generator state must
+    equal those of a sampler that draws at generate() time, step after step; set_state discards a pool drawn ahead."""
+    from mkb_amd import datasets, optim, sampling
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    mk = lambda: sampling.NegativeSampling(size=24, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9)
+    plain, ahead = mk(), mk()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())  # >= 4096 rows: steps row-lazily
+    opt = optim.Adam([ent], lr=1e-3, lazy_rows=True, draw_ahead=ahead)
+    for it in range(7):
+        s = train[it * 64: (it + 1) * 64].contiguous()
+        mode = "head-batch" if it % 2 else "tail-batch"
+        a, b = plain.generate(s, mode), ahead.generate(s, mode)
+        assert torch.equal(a, b), it
+        assert torch.equal(a._mkb_pool.pool, b._mkb_pool.pool) and torch.equal(a._mkb_pool.cnt, b._mkb_pool.cnt)
+        assert torch.equal(a._mkb_pool.touched, b._mkb_pool.touched)
+        ids = torch.randperm(5000, generator=g)[:200].cuda()
+        ent.grad = torch.zeros_like(ent)
+        ent.grad[ids] = 1.0
+        opt.catch_up(ent, ids)
+        ent._mkb_touched = ids
+        opt.step()  # (the catch_up above carried the next pool's draw once a step had been taken)
+        ka, pa = plain.get_state()
+        kb, pb = ahead.get_state()   # the state BEFORE the pool drawn ahead
+        assert pa == pb and np.array_equal(ka, kb), it
+    ahead.set_state(*plain.get_state())  # discards the pool drawn ahead
+    s = train[:64].contiguous()
+    assert torch.equal(plain.generate(s, "tail-batch"), ahead.generate(s, "tail-batch"))
+    plain.check(), ahead.check()

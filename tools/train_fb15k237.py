@@ -38,7 +38,7 @@ def main():
                                         gamma=args.gamma).cuda()
     sampler = sampling.NegativeSampling(size=args.size, train_triples=ds.train, entities=ds.entities,
                                         relations=ds.relations, seed=42)
-    opt = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr, lazy_rows=True)
+    opt = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr, lazy_rows=True, draw_ahead=sampler)
     step = FusedTrainStep(model, args.alpha)
     ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations,
                                batch_size=1024, device="cuda", num_workers=0)
