@@ -88,7 +88,7 @@ def build(device, rank, world, seed=42, parallelism="dims"):
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(len(train_np), generator=g).to(device)
     train, weights = train[perm].contiguous(), weights[perm].contiguous()  # shuffled once (per epoch in a real loop):
-    return dict(model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,  # batches are views
+    return dict(ride=os.environ.get("MKB_BENCH_NO_RIDE", "0") != "1", model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,  # batches are views
                 world=world, n_train=len(train_np), exchange=None, dims=dims)
 
 
@@ -110,8 +110,12 @@ def run_step(ctx, i):
     weight = ctx["weights"][lo: lo + B]
     ex = ctx["exchange"]
     wsum = ex.weight_sum(weight) if ex is not None else None   # global-batch normaliser (all-reduced scalar)
-    neg = ctx["sampler"].generate(sample, mode)
-    loss = ctx["step"](sample, weight, neg, mode, weight_sum=wsum)
+    if ctx.get("ride", True):  # sampler folded into the optimizer's catch-up launch (identical negatives)
+        loss = ctx["step"].sampled(sample, weight, ctx["sampler"], mode, weight_sum=wsum)
+        neg = ctx["step"].negative_sample
+    else:
+        neg = ctx["sampler"].generate(sample, mode)
+        loss = ctx["step"](sample, weight, neg, mode, weight_sum=wsum)
     if ex is not None:
         ex(sample, neg)                                           # sparse all-reduce of the touched gradient rows
     ctx["opt"].step()

@@ -170,6 +170,13 @@ int mkb_adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, 
 int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts, int64_t n_rows,
                           int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float beta1, float beta2,
                           float eps, mkb_sampler_t *draw_ahead, void *stream);
+/* mkb_sampler_generate(sampler, sample, B, mode, neg, pool, pos, cnt, touched) and mkb_adam_rows_catchup over the rows
+ * that batch touches (its pool, heads and tails) as ONE launch that also draws the sampler's next pool: the whole
+ * sampler runs in the shadow of the optimizer's catch-up.  Same outputs, bit for bit, as the two calls (size <= 512). */
+int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                   int64_t n_rows, int64_t D, int64_t step_upto, float beta1, float beta2, float eps,
+                                   mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
+                                   int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream);
 typedef struct {
     float *param, *grad, *exp_avg, *exp_avg_sq; /* a small dense tensor (e.g. the relation table), 16-byte aligned */
     int64_t n;                                  /* elements */

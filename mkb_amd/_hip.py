@@ -81,6 +81,9 @@ _SIGNATURES = {
     "mkb_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double)]),
     "mkb_adam_rows_catchup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                       c_int64, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "mkb_adam_rows_catchup_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                               c_float, c_float, c_float, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_adam_rows_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                    c_int64, c_int64, c_float, c_float, c_float, c_float, POINTER(AdamDense), c_void_p]),
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),

@@ -64,8 +64,9 @@ class Pipeline:
                     raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
                 weight = data["weight"].to(self.device)
                 if fused is not None:
-                    negative_sample = sampling.generate(sample=sample, mode=mode)
-                    error = fused(sample, weight, negative_sample, mode)
+                    # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
+                    error = fused.sampled(sample, weight, sampling, mode)
+                    negative_sample = fused.negative_sample
                 else:
                     score = model(sample)
                     negative_sample = sampling.generate(sample=sample, mode=mode)

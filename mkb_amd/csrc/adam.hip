@@ -115,9 +115,15 @@ struct AdamRowArgs {
     float *dp, *dg, *dm, *dv;
     int64_t dn;
     float d_neg_step, d_sqrt_bc2;
-    // catch-up kernel only: block 0 draws the negative sampler's NEXT pool (pool_draw_body) when first_row_block is set
+    // catch-up kernel only: block 0 draws the negative sampler's NEXT pool (pool_draw_body) when first_row_block is set,
+    // the n_filter blocks behind it filter THIS batch's rows (filter_rows_body), and the row ids may be given as the
+    // three segments pool | heads | tails instead of one array (the array is what the filter blocks are still writing)
     int32_t first_row_block;  // 1 with a draw block, else 0
+    int32_t n_filter;
     DrawArgs draw;
+    FilterArgs filt;
+    const int64_t *seg_pool, *seg_sample;
+    int32_t seg_P, seg_B;
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -180,8 +186,17 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
         pool_draw_body<kCatchThreads>(A.draw, lds_draw);
         return;
     }
-    const int64_t bid = (int64_t)blockIdx.x - A.first_row_block;
-    const int64_t row = A.ids ? A.ids[bid] : bid;
+    if ((int)blockIdx.x < A.first_row_block + A.n_filter) {
+        filter_rows_body(A.filt, (int)blockIdx.x - A.first_row_block, reinterpret_cast<int32_t *>(lds_draw));
+        return;
+    }
+    const int64_t bid = (int64_t)blockIdx.x - A.first_row_block - A.n_filter;
+    int64_t row;
+    if (A.ids) row = A.ids[bid];
+    else if (A.seg_pool) row = bid < A.seg_P ? A.seg_pool[bid]
+                             : (bid < A.seg_P + A.seg_B ? A.seg_sample[3 * (bid - A.seg_P)]
+                                                        : A.seg_sample[3 * (bid - A.seg_P - A.seg_B) + 2]);
+    else row = bid;
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
     __syncthreads();
     const int old = s_old;
@@ -252,6 +267,30 @@ extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_av
     mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
     hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(n + A.first_row_block)), dim3(mkb::kCatchThreads), lds,
                        (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+// mkb_sampler_generate and mkb_adam_rows_catchup(ids = the batch's pool | heads | tails) as ONE launch, plus the draw of
+// the next pool: block 0 draws, the next ceil(B / 4) blocks filter this batch's rows, the rest replay the pending steps.
+extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                              int64_t n_rows, int64_t D, int64_t step_upto, float beta1, float beta2, float eps,
+                                              mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
+                                              int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
+    (void)n_rows;
+    hipStream_t st = (hipStream_t)stream;
+    mkb::AdamRowArgs A{};
+    if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, nullptr, D, step_upto > 0 ? step_upto : 0, 0.f,
+                                beta1, beta2, eps)) return rc;
+    size_t lds = 0;
+    mkb::ProfScope ps(MKB_PROF_SAMPLER, st);
+    if (int rc = mkb::sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
+        return rc;
+    A.first_row_block = 1;
+    A.n_filter = (int32_t)((B + 3) / 4);
+    A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
+    const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
+    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows)), dim3(mkb::kCatchThreads), lds, st, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

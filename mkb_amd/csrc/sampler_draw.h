@@ -158,6 +158,220 @@ __device__ __forceinline__ void pool_draw_body(const DrawArgs &D, unsigned long 
     }
 }
 
+// One filter dictionary (negative_sampling.py:7-28) on the device: an open-addressing hash table whose entries
+// carry everything a row needs in ONE 32-byte load (no dependent key -> offsets -> flags chain), the concatenated
+// sorted true sets, and an entity bitmap for every set of kBitmapMin+ elements (the 3,612-head sets of FB15k-237's
+// hub tails made their rows -- and therefore the whole kernel -- 3x slower when streamed element by element).
+struct HEntry {
+    int64_t key;      // -1 = empty slot
+    int64_t off;      // start of the set in `values`
+    int32_t len;      // elements in the set
+    int32_t flags;    // bit 0: np.in1d takes its sort path for this set; bits 1..: 1 + bitmap index (0 = no bitmap)
+    int64_t pad;
+};
+constexpr int kBitmapMin = 128;
+
+struct Csr {
+    HEntry *htab = nullptr;   // capacity = pow2 >= 2 nk
+    int64_t *values = nullptr;
+    uint32_t *bitmaps = nullptr;  // [n_bitmaps][bm_words]
+    uint32_t hmask = 0;
+    int bm_words = 0;
+    int64_t nk = 0;
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t bloom_hash(int32_t v) { return (uint32_t)v * 2654435761u >> 7; }
+
+__device__ __forceinline__ int64_t lower_bound_dev(const int64_t *__restrict__ a, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one wave per row, 4 rows per workgroup.  Dynamic LDS: the sorted pool (P2 values + P2 positions, shared by the
+// 4 waves) and per wave P kept positions + P ranks + P/32 membership words.
+// Membership is searched the cheap way round: the row's true set streams from global memory with coalesced
+// loads and each element is binary-searched in the SORTED POOL held in LDS (m log P LDS steps), instead of
+// binary-searching global memory for each of the P candidates (P log m dependent global loads).
+struct FilterArgs {
+    const int64_t *sample;   // [B, 3]
+    int B, head_mode;
+    int64_t key_stride;
+    Csr csr;
+    const int64_t *pool;     // [P] the batch's candidate pool and its helper tables (pool_draw_body)
+    const uint8_t *lastflag;
+    const int32_t *sorted_val, *sorted_pos;
+    int K, P, P2, rows_per_wg;
+    int64_t *neg;            // [B, K]
+    int32_t *posmap;         // [B, K] or null
+    uint16_t *cnt;           // [B, P] or null
+    int64_t *touched;        // [P + 2B] or null
+    int64_t *pool_out;       // null, or the caller's copy of the pool (when it was drawn ahead)
+    int32_t *status;
+};
+inline size_t filter_lds_bytes(int P, int P2, int rw) {
+    return sizeof(int32_t) * ((size_t)3 * P2 + (size_t)rw * ((size_t)2 * P + (P + 31) / 32));
+}
+
+// one wave per row, rows_per_wg (<= 4) rows per workgroup; `block` = index among the filter workgroups; lds_i32 =
+// filter_lds_bytes() bytes of dynamic LDS.
+__device__ __forceinline__ void filter_rows_body(const FilterArgs &F, const int block, int32_t *lds_i32) {
+    if (threadIdx.x >= 256) return;  // riding a wider workgroup: the first four waves do the work (the others have left
+                                     // the workgroup, so the barriers below only count these four)
+    const int64_t *__restrict__ sample = F.sample;
+    const int B = F.B, head_mode = F.head_mode, K = F.K, P = F.P, P2 = F.P2, rows_per_wg = F.rows_per_wg;
+    const int64_t key_stride = F.key_stride;
+    const Csr &csr = F.csr;
+    const int64_t *__restrict__ pool = F.pool;
+    const uint8_t *__restrict__ lastflag = F.lastflag;
+    const int32_t *__restrict__ sorted_val = F.sorted_val, *__restrict__ sorted_pos = F.sorted_pos;
+    int64_t *__restrict__ neg = F.neg, *__restrict__ touched = F.touched, *__restrict__ pool_out = F.pool_out;
+    int32_t *__restrict__ posmap = F.posmap, *__restrict__ status = F.status;
+    uint16_t *__restrict__ cnt = F.cnt;
+
+    int32_t *sval = lds_i32, *spos = lds_i32 + P2;
+    if (touched && block == 0)  // id list of the rows a training step reads: pool | heads | tails
+        for (int e = threadIdx.x; e < P; e += 256) touched[e] = pool[e];
+    if (pool_out && block == 0)  // the pool was drawn ahead of this call: hand the caller its copy
+        for (int e = threadIdx.x; e < P; e += 256) pool_out[e] = pool[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int words = (P + 31) / 32;
+    const int wslot = wave < rows_per_wg ? wave : 0;  // idle waves alias slot 0 but never touch it
+    int32_t *kept = lds_i32 + 2 * P2 + (size_t)wslot * (2 * P + words);  // kept[rho] = position of the rho-th survivor
+    int32_t *rank = kept + P;                                            // rank[p] = rho or -1
+    uint32_t *member = reinterpret_cast<uint32_t *>(rank + P);           // bit p: pool[p] is in the row's true set
+    // Bloom bitmap of the pool's entity ids: 32 bits per pool slot (P2 words), one hash
+    uint32_t *bloom = reinterpret_cast<uint32_t *>(lds_i32 + 2 * P2 + (size_t)rows_per_wg * (2 * P + words));
+    const uint32_t bloom_mask = (uint32_t)P2 * 32u - 1u;
+    for (int e = threadIdx.x; e < P2; e += 256) { sval[e] = sorted_val[e]; spos[e] = sorted_pos[e]; bloom[e] = 0; }
+    if (wave < rows_per_wg) for (int w = lane; w < words; w += 64) member[w] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < P2; e += 256) {
+        if (spos[e] >= 0) {
+            const uint32_t hb = bloom_hash(sval[e]) & bloom_mask;
+            atomicOr(&bloom[hb >> 5], 1u << (hb & 31));
+        }
+    }
+    __syncthreads();
+    const int i = block * rows_per_wg + wave;
+    const bool valid = wave < rows_per_wg && i < B;
+    bool found = false;
+    int nf = 0;
+    if (valid) {
+        const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
+        if (touched && lane == 0) { touched[P + i] = h; touched[P + B + i] = t; }
+        const int64_t key = head_mode ? r * key_stride + t : h * key_stride + r;
+        HEntry ent{-1, 0, 0, 0, 0};
+        if (csr.nk > 0) {
+            uint32_t slot = (uint32_t)mix64((uint64_t)key) & csr.hmask;
+            for (;;) {
+                ent = csr.htab[slot];
+                if (ent.key == key || ent.key < 0) break;
+                slot = (slot + 1) & csr.hmask;
+            }
+        }
+        found = ent.key == key;
+        if (found) {
+            const int m = ent.len;
+            const int64_t *rec = csr.values + ent.off;
+            const bool sortpath = ent.flags & 1;
+            const int bm = (ent.flags >> 1) - 1;
+            if (bm >= 0) {  // big set: one independent bitmap probe per pool entry
+                const uint32_t *bits = csr.bitmaps + (size_t)bm * csr.bm_words;
+                for (int base = 0; base < P; base += 64) {
+                    const int p = base + lane;
+                    bool mem = false;
+                    if (p < P) {
+                        const int64_t c = pool[p];
+                        mem = (bits[c >> 5] >> (c & 31)) & 1u;
+                    }
+                    const unsigned long long b = __ballot(mem);
+                    if (lane == 0) {
+                        member[base >> 5] = (uint32_t)b;
+                        if ((base >> 5) + 1 < words) member[(base >> 5) + 1] = (uint32_t)(b >> 32);
+                    }
+                }
+            } else
+            // Stream the true set 8 elements per lane at a time (independent coalesced loads in flight together),
+            // probe a Bloom bitmap of the pool first: almost every element misses and costs one LDS read; the
+            // rare hit is confirmed (and its positions found) by binary search in the sorted pool.
+            for (int e0 = 0; e0 < m; e0 += 64 * 8) {
+                int64_t v64[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    v64[u] = e < m ? rec[e] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (v64[u] < 0 || v64[u] >= INT32_MAX) continue;
+                    const int32_t v = (int32_t)v64[u];
+                    const uint32_t hb = bloom_hash(v) & bloom_mask;
+                    if (!((bloom[hb >> 5] >> (hb & 31)) & 1u)) continue;
+                    int lo = 0, hi = P2;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (sval[mid] < v) lo = mid + 1; else hi = mid;
+                    }
+                    for (; lo < P2 && sval[lo] == v; ++lo) {
+                        const int p = spos[lo];
+                        atomicOr(&member[p >> 5], 1u << (p & 31));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int base = 0; base < P; base += 64) {
+                const int p = base + lane;
+                bool keep = false;
+                if (p < P) {
+                    const bool mem = (member[p >> 5] >> (p & 31)) & 1u;
+                    keep = !mem && (!sortpath || lastflag[p] != 0);
+                }
+                const unsigned long long b = __ballot(keep);
+                const int rho = nf + __popcll(b & ((1ull << lane) - 1ull));
+                if (keep) kept[rho] = p;
+                if (p < P) rank[p] = keep ? rho : -1;
+                nf += __popcll(b);
+            }
+        }
+    }
+    __syncthreads();  // kept[] / rank[] visible to every lane of the wave that wrote them
+    if (!valid) return;
+    if (!found || nf == 0) {
+        if (lane == 0) {
+            atomicCAS(&status[0], 0, found ? (int)MKB_ERR_EMPTY : (int)MKB_ERR_KEY);
+            atomicMin(&status[1], i);
+        }
+        for (int j = lane; j < K; j += 64) {
+            neg[(int64_t)i * K + j] = 0;
+            if (posmap) posmap[(int64_t)i * K + j] = 0;
+        }
+        if (cnt) for (int p = lane; p < P; p += 64) cnt[(int64_t)i * P + p] = 0;
+        return;
+    }
+    for (int j = lane; j < K; j += 64) {  // cyclic fill: concat(f, f, ...)[:K]   (negative_sampling.py:176-195)
+        const int pp = kept[j % nf];
+        neg[(int64_t)i * K + j] = pool[pp];
+        if (posmap) posmap[(int64_t)i * K + j] = pp;
+    }
+    if (cnt) {  // multiplicity of pool position p among the K slots of this row
+        for (int p = lane; p < P; p += 64) {
+            const int rho = rank[p];
+            cnt[(int64_t)i * P + p] = (rho >= 0 && rho < K) ? (uint16_t)((K - 1 - rho) / nf + 1) : (uint16_t)0;
+        }
+    }
+}
+
 }  // namespace mkb
 
 // sampler.hip: hand the next pool draw of `s` to another launch (fills *D, returns the dynamic LDS it needs); the next
@@ -165,4 +379,10 @@ __device__ __forceinline__ void pool_draw_body(const DrawArgs &D, unsigned long 
 struct mkb_sampler;
 namespace mkb {
 bool sampler_draw_ahead(mkb_sampler *s, DrawArgs *D, size_t *lds_bytes);
+// The whole of mkb_sampler_generate for another launch to carry: *F = the row filter of THIS batch (its pool must have
+// been drawn ahead; if not, the draw kernel is launched on `st` first), *D = the draw of the NEXT pool into the other
+// buffer.  *pool_ids = this batch's pool on the device (valid until the generate after next).
+int sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode, int64_t *neg, int64_t *pool, int32_t *pos,
+                 uint16_t *cnt, int64_t *touched, FilterArgs *F, DrawArgs *D, const int64_t **pool_ids, size_t *lds_bytes,
+                 hipStream_t st);
 }

@@ -98,6 +98,20 @@ class FusedTrainStep:
         return _hip.Grads(m.entity_embedding.grad.data_ptr(), m.relation_embedding.grad.data_ptr(),
                           m.modulus.grad.data_ptr() if m.name == "pRotatE" else None)
 
+    def sampled(self, sample, weight, sampler, mode, weight_sum=None):
+        """``step(sample, weight, sampler.generate(sample, mode), mode)`` with the sampler folded into the optimizer's
+        catch-up launch when the entity table steps row-lazily (``mkb_amd.optim.Adam(lazy_rows=True)``): no sampler
+        launch, identical negatives.  The negatives of the call stay available as ``self.negative_sample``."""
+        ent = self.model.entity_embedding
+        lazy = getattr(ent, "_mkb_lazy", None)
+        sample = _hip.contiguous(sample, torch.int64)
+        if lazy is not None and sampler.size <= 512 and sample.is_cuda:
+            neg = sampler.generate_with_catch_up(sample, mode, lazy, ent)
+        else:
+            neg = sampler.generate(sample=sample, mode=mode)
+        self.negative_sample = neg
+        return self(sample, weight, neg, mode, weight_sum=weight_sum)
+
     def __call__(self, sample, weight, negative_sample, mode, weight_sum=None):
         """``weight_sum``: optional device scalar = sum of weights of the WHOLE batch when these rows are one
         data-parallel shard of it (see mkb_amd.parallel); the returned loss is then this shard's share."""
@@ -120,7 +134,9 @@ class FusedTrainStep:
         lazy = getattr(ent, "_mkb_lazy", None)
         if lazy is not None:  # row-lazy Adam: the rows this step reads must be current before the forward pass
             ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
-            lazy.catch_up(ent, ids)
+            done = lazy._state(ent).get("caught_up")
+            if done is None or done[0] is not ids or done[1] != lazy._state(ent)["n"]:  # (sampled() already did it)
+                lazy.catch_up(ent, ids)
             ent._mkb_touched = ids
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),

@@ -145,6 +145,37 @@ class NegativeSampling:
         neg._mkb_pool.touched = touched
         return neg
 
+    def generate_with_catch_up(self, sample, mode, optimizer, param):
+        """``generate(sample, mode)`` and ``optimizer.catch_up(param, rows this batch touches)`` as ONE launch that also
+        draws the next pool (``mkb_adam_rows_catchup_generate``): the sampler costs no launch of its own.  ``optimizer``:
+        a ``mkb_amd.optim.Adam(lazy_rows=True)`` holding ``param`` (the entity table) row-lazily.  Same negatives, pool
+        and multiplicities, bit for bit, as ``generate``."""
+        if mode not in ("head-batch", "tail-batch"):
+            raise ValueError("mode must be 'head-batch' or 'tail-batch'")
+        sample = _hip.contiguous(sample, torch.int64)
+        _hip.require_device(param, sample)
+        dev = sample.device
+        self._ensure_handle(dev)
+        B, K = sample.shape[0], self.size
+        neg = torch.empty((B, K), dtype=torch.int64, device=dev)
+        pool = torch.empty(2 * K, dtype=torch.int64, device=dev)
+        pos = torch.empty((B, K), dtype=torch.int32, device=dev)
+        cnt = torch.empty((B, 2 * K), dtype=torch.uint16, device=dev)
+        touched = torch.empty(2 * K + 2 * B, dtype=torch.int64, device=dev)
+        mode_id = _hip.mode_id(mode)
+        st = optimizer._state(param)
+        upto = st["n"]
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().mkb_adam_rows_catchup_generate(
+                _hip.ptr(param.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
+                _hip.ptr(optimizer._consts(st, max(upto, 1))), param.shape[0], param.shape[1], upto, optimizer.betas[0],
+                optimizer.betas[1], optimizer.eps, self._handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg), _hip.ptr(pool),
+                _hip.ptr(pos), _hip.ptr(cnt), _hip.ptr(touched), _hip.stream_ptr()), "mkb_adam_rows_catchup_generate")
+        st["caught_up"] = (touched, upto)
+        neg._mkb_pool = PoolInfo(pool, pos, cnt, K, mode_id, sample)
+        neg._mkb_pool.touched = touched
+        return neg
+
     def check(self):
         """Raise what the reference would have raised for the batches generated so far (synchronises)."""
         if self._handle is None:

@@ -139,3 +139,45 @@ def test_pool_drawn_ahead_inside_the_optimizer_launch_is_bit_identical():
     s = train[:64].contiguous()
     assert torch.equal(plain.generate(s, "tail-batch"), ahead.generate(s, "tail-batch"))
     plain.check(), ahead.check()
+
+
+def test_sampler_riding_the_catch_up_launch_is_bit_identical():
+    """mkb_adam_rows_catchup_generate: draw-ahead + this batch's filter + the row catch-up in one launch.  Every output
+    of generate (negatives, pool, position map, multiplicities, touched rows) and the optimizer's tables must equal the
+    separate calls', step after step, including the first step (nothing pending, pool not drawn ahead yet)."""
+    from mkb_amd import datasets, optim, sampling
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    mk = lambda: sampling.NegativeSampling(size=24, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9)
+    tables = []
+    for ride in (False, True):
+        sam = mk()
+        g = torch.Generator(device="cpu").manual_seed(1)
+        ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())  # >= 4096 rows: steps row-lazily
+        opt = optim.Adam([ent], lr=1e-3, lazy_rows=True)
+        outs = []
+        for it in range(7):
+            s = train[it * 61: it * 61 + 61].contiguous()  # 61 rows: the last filter workgroup is ragged
+            mode = "head-batch" if it % 2 else "tail-batch"
+            if ride:
+                neg = sam.generate_with_catch_up(s, mode, opt, ent)
+            else:
+                neg = sam.generate(s, mode)
+                opt.catch_up(ent, neg._mkb_pool.touched)
+            info = neg._mkb_pool
+            outs.append((neg.clone(), info.pool.clone(), info.pos.clone(), info.cnt.clone(), info.touched.clone()))
+            ids = info.touched
+            ent.grad = torch.zeros_like(ent)
+            ent.grad[torch.unique(ids)] = 0.5
+            ent._mkb_touched = ids
+            opt.step()
+        opt.flush()
+        sam.check()
+        tables.append((outs, ent.detach().clone(), sam.get_state()))
+    for a, b in zip(tables[0][0], tables[1][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(tables[0][1], tables[1][1])
+    (ka, pa), (kb, pb) = tables[0][2], tables[1][2]
+    assert pa == pb and np.array_equal(ka, kb)  # the riding sampler holds a pool drawn ahead: same logical state

@@ -47,8 +47,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for data in batches:
-            neg = sampler.generate(data["sample"], data["mode"])
-            loss = step(data["sample"], data["weight"], neg, data["mode"])
+            loss = step.sampled(data["sample"], data["weight"], sampler, data["mode"])
             opt.step()
             opt.zero_grad()
             n_steps += 1
