@@ -100,8 +100,10 @@ def run_step(ctx, i):
         gb = world * B
         lo = (i * gb) % (n - gb)
         sample, weight = ctx["train"][lo: lo + gb], ctx["weights"][lo: lo + gb]
-        neg = ctx["sampler"].generate(sample, mode)
-        loss = ctx["step"](sample, weight, neg, mode)  # one all-reduce of the partial scores inside
+        if ctx.get("ride", True):
+            loss = ctx["step"].sampled(sample, weight, ctx["sampler"], mode)  # one all-reduce of the partial scores inside
+        else:
+            loss = ctx["step"](sample, weight, ctx["sampler"].generate(sample, mode), mode)
         ctx["opt"].step()
         ctx["opt"].zero_grad()
         return loss

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
         return;
     }
     if ((int)blockIdx.x < A.first_row_block + A.n_filter) {
-        filter_rows_body(A.filt, (int)blockIdx.x - A.first_row_block, reinterpret_cast<int32_t *>(lds_draw));
+        filter_rows_body<kCatchThreads>(A.filt, (int)blockIdx.x - A.first_row_block, reinterpret_cast<int32_t *>(lds_draw));
         return;
     }
     const int64_t bid = (int64_t)blockIdx.x - A.first_row_block - A.n_filter;
@@ -272,7 +272,7 @@ extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_av
 }
 
 // mkb_sampler_generate and mkb_adam_rows_catchup(ids = the batch's pool | heads | tails) as ONE launch, plus the draw of
-// the next pool: block 0 draws, the next ceil(B / 4) blocks filter this batch's rows, the rest replay the pending steps.
+// the next pool: block 0 draws, the next ceil(B / 16) blocks filter this batch's rows, the rest replay the pending steps.
 extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                                               int64_t n_rows, int64_t D, int64_t step_upto, float beta1, float beta2, float eps,
                                               mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
@@ -287,9 +287,15 @@ extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, floa
     if (int rc = mkb::sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
         return rc;
     A.first_row_block = 1;
-    A.n_filter = (int32_t)((B + 3) / 4);
+    A.n_filter = (int32_t)((B + 15) / 16);  // one wave per row, 16 rows per 1024-lane workgroup
     A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
     const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
+    static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)
+    if (!big_lds) {
+        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mkb::adam_rows_catchup_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        big_lds = true;
+    }
     hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows)), dim3(mkb::kCatchThreads), lds, st, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void pool_draw_kernel(DrawArgs D) {
 
 __global__ __launch_bounds__(256) void filter_rows_kernel(FilterArgs F) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds_i32[];
-    filter_rows_body(F, (int)blockIdx.x, lds_i32);
+    filter_rows_body<256>(F, (int)blockIdx.x, lds_i32);
 }
 
 static int upload_csr(Csr &c, const int64_t *keys, int64_t nk, const int64_t *offsets, const int64_t *values, int64_t P,
@@ -245,11 +245,11 @@ int mkb::sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode
     MKB_REQUIRE(s->P() <= 1024, "riding the optimizer launch supports size <= 512");
     bool was_ahead = false;
     if (int rc = take_pool(s, pool, st, &was_ahead)) return rc;
-    *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, 4);
+    *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, 16);  // 1024-lane blocks
     *pool_ids = F->pool;
     *D = s->draw_args(s->cur ^ 1, nullptr, /*save_prev=*/true);  // the next pool, into the other buffer
     s->drawn_ahead = true;
-    const size_t a = filter_lds_bytes(F->P, F->P2, 4), b = draw_lds_bytes(D->P, D->P2);
+    const size_t a = filter_lds_bytes(F->P, F->P2, 16), b = draw_lds_bytes(D->P, D->P2);
     *lds_bytes = a > b ? a : b;
     return MKB_OK;
 }

@@ -222,11 +222,10 @@ inline size_t filter_lds_bytes(int P, int P2, int rw) {
     return sizeof(int32_t) * ((size_t)3 * P2 + (size_t)rw * ((size_t)2 * P + (P + 31) / 32));
 }
 
-// one wave per row, rows_per_wg (<= 4) rows per workgroup; `block` = index among the filter workgroups; lds_i32 =
-// filter_lds_bytes() bytes of dynamic LDS.
+// one wave per row, rows_per_wg (<= NT / 64) rows per NT-lane workgroup; `block` = index among the filter workgroups;
+// lds_i32 = filter_lds_bytes() bytes of dynamic LDS.
+template <int NT>
 __device__ __forceinline__ void filter_rows_body(const FilterArgs &F, const int block, int32_t *lds_i32) {
-    if (threadIdx.x >= 256) return;  // riding a wider workgroup: the first four waves do the work (the others have left
-                                     // the workgroup, so the barriers below only count these four)
     const int64_t *__restrict__ sample = F.sample;
     const int B = F.B, head_mode = F.head_mode, K = F.K, P = F.P, P2 = F.P2, rows_per_wg = F.rows_per_wg;
     const int64_t key_stride = F.key_stride;
@@ -240,9 +239,9 @@ __device__ __forceinline__ void filter_rows_body(const FilterArgs &F, const int 
 
     int32_t *sval = lds_i32, *spos = lds_i32 + P2;
     if (touched && block == 0)  // id list of the rows a training step reads: pool | heads | tails
-        for (int e = threadIdx.x; e < P; e += 256) touched[e] = pool[e];
+        for (int e = threadIdx.x; e < P; e += NT) touched[e] = pool[e];
     if (pool_out && block == 0)  // the pool was drawn ahead of this call: hand the caller its copy
-        for (int e = threadIdx.x; e < P; e += 256) pool_out[e] = pool[e];
+        for (int e = threadIdx.x; e < P; e += NT) pool_out[e] = pool[e];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int words = (P + 31) / 32;
     const int wslot = wave < rows_per_wg ? wave : 0;  // idle waves alias slot 0 but never touch it
@@ -252,10 +251,10 @@ __device__ __forceinline__ void filter_rows_body(const FilterArgs &F, const int 
     // Bloom bitmap of the pool's entity ids: 32 bits per pool slot (P2 words), one hash
     uint32_t *bloom = reinterpret_cast<uint32_t *>(lds_i32 + 2 * P2 + (size_t)rows_per_wg * (2 * P + words));
     const uint32_t bloom_mask = (uint32_t)P2 * 32u - 1u;
-    for (int e = threadIdx.x; e < P2; e += 256) { sval[e] = sorted_val[e]; spos[e] = sorted_pos[e]; bloom[e] = 0; }
+    for (int e = threadIdx.x; e < P2; e += NT) { sval[e] = sorted_val[e]; spos[e] = sorted_pos[e]; bloom[e] = 0; }
     if (wave < rows_per_wg) for (int w = lane; w < words; w += 64) member[w] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < P2; e += 256) {
+    for (int e = threadIdx.x; e < P2; e += NT) {
         if (spos[e] >= 0) {
             const uint32_t hb = bloom_hash(sval[e]) & bloom_mask;
             atomicOr(&bloom[hb >> 5], 1u << (hb & 31));

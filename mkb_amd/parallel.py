@@ -219,6 +219,19 @@ class DimShardedStep:
         self.rank, self.world, self.gamma, self.uses_gamma = local_model._dim_shard
         self.micro_batches = (2 if self.world > 1 else 1) if micro_batches is None else micro_batches
 
+    def sampled(self, sample, weight, sampler, mode):
+        """``step(sample, weight, sampler.generate(sample, mode), mode)`` with the sampler folded into the row-lazy
+        optimizer's catch-up launch (see ``FusedTrainStep.sampled``); every rank draws the same negatives."""
+        ent = self.model.entity_embedding
+        lazy = getattr(ent, "_mkb_lazy", None)
+        sample = self._hip.contiguous(sample, torch.int64)
+        if lazy is not None and sampler.size <= 512 and sample.is_cuda:
+            neg = sampler.generate_with_catch_up(sample, mode, lazy, ent)
+        else:
+            neg = sampler.generate(sample=sample, mode=mode)
+        self.negative_sample = neg
+        return self(sample, weight, neg, mode)
+
     def __call__(self, sample, weight, negative_sample, mode):
         _hip, m = self._hip, self.model
         info = negative_sample._mkb_pool
@@ -237,7 +250,9 @@ class DimShardedStep:
         lazy = getattr(ent, "_mkb_lazy", None)
         if lazy is not None:
             ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
-            lazy.catch_up(ent, ids)
+            done = lazy._state(ent).get("caught_up")
+            if done is None or done[0] is not ids or done[1] != lazy._state(ent)["n"]:  # (sampled() already did it)
+                lazy.catch_up(ent, ids)
             ent._mkb_touched = ids
         lib, tb = _hip.lib(), m._tables()
         nmb = max(1, min(self.micro_batches, B // 8))

@@ -31,8 +31,7 @@ def main(world):
         lo = (i * gb) % (len(train_np) - gb)
         s, ww = train[lo: lo + gb], w[lo: lo + gb]
         mode = "head-batch" if i % 2 == 0 else "tail-batch"
-        neg = ns.generate(s, mode)
-        step(s, ww, neg, mode)
+        step.sampled(s, ww, ns, mode)
         opt.step(); opt.zero_grad()
 
     for i in range(10):
