@@ -28,7 +28,7 @@ def main(path):
         print(f"{k:112s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:9.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100 * a[1] / tot:6.2f}")
 
 
-def timeline(path, step_kernel="pool_draw_kernel", which=-3):
+def timeline(path, step_kernel="adam_rows_catchup_kernel", which=-3):
     """One training step as a timeline: start offset, duration and the idle gap before every kernel."""
     con = sqlite3.connect(path)
     rows = con.execute("select name, start, end from kernels order by start").fetchall()
