@@ -287,7 +287,7 @@ extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, floa
     if (int rc = mkb::sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
         return rc;
     A.first_row_block = 1;
-    A.n_filter = (int32_t)((B + 15) / 16);  // one wave per row, 16 rows per 1024-lane workgroup
+    A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
     A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
     const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
     static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)

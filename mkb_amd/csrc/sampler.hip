@@ -245,11 +245,14 @@ int mkb::sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode
     MKB_REQUIRE(s->P() <= 1024, "riding the optimizer launch supports size <= 512");
     bool was_ahead = false;
     if (int rc = take_pool(s, pool, st, &was_ahead)) return rc;
-    *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, 16);  // 1024-lane blocks
+    // 1024-lane carrier blocks: one wave per row, as many rows per block as fit the carrier's 96 KB dynamic-LDS opt-in
+    int rw = 16;
+    while (rw > 1 && filter_lds_bytes(s->P(), s->P2(), rw) > (size_t)96 * 1024) --rw;
+    *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, rw);
     *pool_ids = F->pool;
     *D = s->draw_args(s->cur ^ 1, nullptr, /*save_prev=*/true);  // the next pool, into the other buffer
     s->drawn_ahead = true;
-    const size_t a = filter_lds_bytes(F->P, F->P2, 16), b = draw_lds_bytes(D->P, D->P2);
+    const size_t a = filter_lds_bytes(F->P, F->P2, rw), b = draw_lds_bytes(D->P, D->P2);
     *lds_bytes = a > b ? a : b;
     return MKB_OK;
 }

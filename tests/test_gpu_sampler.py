@@ -141,7 +141,8 @@ def test_pool_drawn_ahead_inside_the_optimizer_launch_is_bit_identical():
     plain.check(), ahead.check()
 
 
-def test_sampler_riding_the_catch_up_launch_is_bit_identical():
+@pytest.mark.parametrize("size", [24, 512])
+def test_sampler_riding_the_catch_up_launch_is_bit_identical(size):
     """mkb_adam_rows_catchup_generate: draw-ahead + this batch's filter + the row catch-up in one launch.  Every output
     of generate (negatives, pool, position map, multiplicities, touched rows) and the optimizer's tables must equal the
     separate calls', step after step, including the first step (nothing pending, pool not drawn ahead yet)."""
@@ -149,12 +150,15 @@ def test_sampler_riding_the_catch_up_launch_is_bit_identical():
 
     ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
-    mk = lambda: sampling.NegativeSampling(size=24, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9)
+    if size > 100:  # a sparse graph so that a 1024-candidate pool is never filtered empty
+        ds = datasets.Wn18rr(batch_size=64, shuffle=False, seed=42, num_workers=0)
+        train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    mk = lambda: sampling.NegativeSampling(size=size, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9)
     tables = []
     for ride in (False, True):
         sam = mk()
         g = torch.Generator(device="cpu").manual_seed(1)
-        ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())  # >= 4096 rows: steps row-lazily
+        ent = torch.nn.Parameter(torch.randn(max(5000, len(ds.entities)), 64, generator=g).cuda())  # >= 4096 rows: row-lazy
         opt = optim.Adam([ent], lr=1e-3, lazy_rows=True)
         outs = []
         for it in range(7):
