@@ -202,7 +202,8 @@ int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode,
 
 /* ---- per-kernel timing (measurement aid, no reference counterpart) -------------------------------------
  * When enabled, the launches of the named kernel class are bracketed by hipEvents recorded on the SAME stream
- * the kernel is launched on.  mkb_profile_read synchronises, returns the number of bracketed launches and
+ * the kernel is launched on (on = N > 1: every N-th launch only -- the two event records cost ~6 us of stream time
+ * each, which a sampled measurement keeps out of most steps).  mkb_profile_read synchronises, returns the number of bracketed launches and
  * their summed duration in milliseconds, and resets the counters.  kernel: 0 = pooled backward (the dq and dx passes
  * in one launch; for ComplEx / DistMult the dQ GEMM),
  * 1 = pooled forward, 2 = Adam, 3 = sampler (draw + filter), 4 = adversarial loss, 5 = general forward,

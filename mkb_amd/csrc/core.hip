@@ -17,6 +17,8 @@ int set_error(int code, const char *fmt, ...) {
 constexpr int kProfSlots = 8192;
 struct ProfState {
     bool on = false;
+    int every = 1;   // bracket every `every`-th launch (two event records cost ~6 us of stream time each)
+    int seen = 0;
     int n = 0;
     hipEvent_t *start = nullptr, *stop = nullptr;
 };
@@ -25,6 +27,7 @@ static ProfState g_prof[MKB_PROF_KINDS];
 ProfScope::ProfScope(int kind_, hipStream_t st_) : kind(kind_), st(st_), slot(-1) {
     ProfState &p = g_prof[kind];
     if (!p.on || p.n >= kProfSlots) return;
+    if (p.seen++ % p.every != 0) return;
     if (!p.start) {
         p.start = new hipEvent_t[kProfSlots]();
         p.stop = new hipEvent_t[kProfSlots]();
@@ -46,6 +49,8 @@ ProfScope::~ProfScope() {
 extern "C" int mkb_profile_enable(int kernel, int on) {
     MKB_REQUIRE(kernel >= 0 && kernel < MKB_PROF_KINDS, "bad kernel kind");
     mkb::g_prof[kernel].on = on != 0;
+    mkb::g_prof[kernel].every = on > 1 ? on : 1;
+    mkb::g_prof[kernel].seen = 0;
     return MKB_OK;
 }
 
