@@ -19,8 +19,15 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
+from ..sampling.negative_sampling import PoolInfo
 
 __all__ = ["BaseModel"]
+
+
+# Negatives without a pool description are scanned for one (PoolInfo.discover) when they are big enough for the pooled
+# kernels to pay for the scan; set AUTO_POOL = False to always take the general kernels.
+AUTO_POOL = True
+AUTO_POOL_MIN_SLOTS = 32768
 
 
 class _ScoreFn(torch.autograd.Function):
@@ -185,6 +192,10 @@ class BaseModel(Base):
         cand = None
         if mode_id != _hip.MODE_DEFAULT:
             pooled = getattr(negative_sample, "_mkb_pool", None)
+            if (pooled is None and AUTO_POOL and negative_sample.dim() == 2 and negative_sample.shape[1] <= 512
+                    and negative_sample.numel() >= AUTO_POOL_MIN_SLOTS and PoolInfo.enabled):
+                # negatives from somewhere else (the reference's sampler, a checkpointed batch): look for the shared pool
+                pooled = PoolInfo.discover(_hip.contiguous(negative_sample, torch.int64), sample, mode_id)
             if pooled is not None and pooled.usable_for(self, sample, mode_id):
                 from ..fused import pooled_forward
                 return pooled_forward(self, sample, pooled, mode_id).view(shape)

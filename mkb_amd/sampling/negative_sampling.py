@@ -73,6 +73,24 @@ class PoolInfo:
         self.sample_ptr, self.batch = sample.data_ptr(), sample.shape[0]
         self.touched = None  # [2K + 2B] entity rows a step on this batch reads: pool | heads | tails
 
+    @classmethod
+    def discover(cls, negative_sample, sample, mode_id):
+        """Shared-pool description of ARBITRARY negatives ``[B, K]`` (e.g. the reference's own CPU sampler's output moved
+        to the device): if the batch draws on at most 2K distinct entities -- which is what mkb's sampler always
+        produces, one pool per batch -- the pooled kernels apply.  Costs one ``torch.unique`` (a sort and a host sync);
+        returns ``None`` when the negatives are too diverse."""
+        B, K = negative_sample.shape
+        uniq, inv = torch.unique(negative_sample, return_inverse=True)
+        U = uniq.numel()
+        if U > 2 * K:
+            return None
+        dev = negative_sample.device
+        pool = torch.zeros(2 * K, dtype=torch.int64, device=dev)
+        pool[:U] = uniq
+        cnt = torch.zeros((B, 2 * K), dtype=torch.int32, device=dev)
+        cnt.scatter_add_(1, inv, torch.ones_like(inv, dtype=torch.int32))
+        return cls(pool, inv.to(torch.int32).contiguous(), cnt.to(torch.uint16), K, mode_id, sample)
+
     def usable_for(self, model, sample, mode_id):
         return (self.enabled and mode_id == self.mode_id and sample.shape[0] == self.batch
                 and _hip.lib().mkb_pool_supported(model._tables(), self.batch, self.size)

@@ -331,7 +331,7 @@ def test_large_pool_falls_back_to_general_kernels():
 
 
 @pytest.mark.parametrize("name,hidden", [("RotatE", 1000), ("ComplEx", 1000), ("TransE", 1000)])
-def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name, hidden):
+def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name, hidden, monkeypatch):
     """BASELINE full size (FB15k-237, hidden 1000, K=256, B=1024): the oracle needs ~80 s per step here, so
     (a) the fused pooled step is checked against the GENERAL kernels (an independent implementation: per-row LDS
         query + wave-per-candidate forward, atomics backward) on every score, the loss and both dense gradients;
@@ -340,7 +340,9 @@ def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name,
     from mkb_amd import datasets, losses, models, sampling
     from mkb_amd.fused import FusedTrainStep
     from oracle import scoring
+    import mkb_amd.models.base as model_base
 
+    monkeypatch.setattr(model_base, "AUTO_POOL", False)  # the plain copy below must really take the general kernels
     ds = datasets.Fb15k237(batch_size=1024, shuffle=False, seed=42, num_workers=0)
     torch.manual_seed(42)
     m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=9.0)
@@ -407,3 +409,38 @@ def test_every_launch_configuration_agrees_with_general_kernels(name, hidden, mo
         np.testing.assert_allclose(got["pooled"][2], got["general"][2], rtol=0, atol=1e-5)
         np.testing.assert_allclose(got["pooled"][3], got["general"][3], rtol=1e-4, atol=1e-5)
     ns.check()
+
+
+@pytest.mark.parametrize("name", ["RotatE", "ComplEx"])
+def test_foreign_negatives_are_scanned_for_their_shared_pool(name, monkeypatch):
+    """Negatives that do not come from mkb_amd's sampler (here: the oracle's restatement of the reference sampler, made
+    on the host) carry no pool description; a big enough batch is scanned for one (PoolInfo.discover) and then scored
+    by the pooled kernels.  Scores and gradients must equal the general kernels'."""
+    from mkb_amd import datasets, losses, models
+    from mkb_amd.sampling.negative_sampling import PoolInfo
+    import mkb_amd.models.base as model_base
+    from oracle import sampler as oracle_sampler
+
+    ds = datasets.Fb15k237(batch_size=512, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(1)
+    m = getattr(models, name)(hidden_dim=96, entities=ds.entities, relations=ds.relations, gamma=9.0).cuda()
+    on = oracle_sampler.NegativeSampling(size=64, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=5)
+    train = np.asarray(ds.train, dtype=np.int64)
+    s_np = train[np.random.RandomState(2).randint(len(train), size=512)]
+    neg_np, _ = on.generate(s_np, "head-batch")
+    s, neg, w = torch.as_tensor(s_np).cuda(), torch.as_tensor(neg_np).cuda(), (torch.rand(512) + 0.1).cuda()
+    found = []
+    real = PoolInfo.discover.__func__
+    monkeypatch.setattr(PoolInfo, "discover", classmethod(lambda cls, *a: found.append(real(cls, *a)) or found[-1]))
+    got = {}
+    for auto in (True, False):
+        monkeypatch.setattr(model_base, "AUTO_POOL", auto)
+        m.zero_grad(set_to_none=True)
+        sc = m(s, neg, "head-batch")
+        losses.Adversarial(alpha=1.0)(m(s), sc, w).backward()
+        got[auto] = (sc.detach().cpu().numpy(), m.entity_embedding.grad.cpu().numpy().copy(),
+                     m.relation_embedding.grad.cpu().numpy().copy())
+    assert len(found) == 1 and found[0] is not None and found[0].pool.numel() == 128  # 512 x 64 slots: scanned once
+    np.testing.assert_allclose(got[True][0], got[False][0], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(got[True][1], got[False][1], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got[True][2], got[False][2], rtol=1e-4, atol=1e-5)

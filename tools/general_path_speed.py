@@ -1,5 +1,6 @@
-"""Throughput of the GENERAL (any candidates) kernels at the headline shape: the reference's low-level loop
-(README.md:448-474) with negatives that carry no shared-pool description, autograd, torch-style dense Adam kernel.
+"""Throughput of the reference's low-level loop (README.md:448-474) at the headline shape with negatives that carry NO
+shared-pool description (a plain LongTensor), autograd and the dense Adam kernel: once with the pool scan that
+mkb_amd.models applies to such negatives (PoolInfo.discover -> pooled kernels), once on the general kernels.
     python tools/general_path_speed.py"""
 import sys
 import time
@@ -29,13 +30,18 @@ def step(i):
     opt.zero_grad()
 
 
-for i in range(5):
-    step(i)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 30
-for i in range(n):
-    step(5 + i)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / n
-print(f"GENERAL path: {dt * 1e3:.3f} ms/step = {1024 * 257 / dt / 1e6:.0f} M scored triples/s")
+import mkb_amd.models.base as model_base  # noqa: E402
+
+for auto in (True, False):
+    model_base.AUTO_POOL = auto
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 30
+    for i in range(n):
+        step(5 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"plain negatives, {'pool scan + pooled kernels' if auto else 'general kernels'}: {dt * 1e3:.3f} ms/step = "
+          f"{1024 * 257 / dt / 1e6:.0f} M scored triples/s")
