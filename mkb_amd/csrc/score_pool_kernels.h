@@ -449,11 +449,7 @@ __device__ __forceinline__ void pool_bwd_q_body(const PoolArgs &A, const int blo
     float *dQs = A.dQ + (int64_t)sl * A.B * A.De;
 #pragma unroll
     for (int r = 0; r < TI; ++r)
-#ifdef MKB_EXP_NO_DQ_STORE
-        if (i0 + r < A.B && A.P < 0) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
-#else
         if (i0 + r < A.B) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
-#endif
     if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
         extra = wave_sum(extra);
         if ((tid & 63) == 0) s_red[tid >> 6] = extra;
@@ -613,15 +609,8 @@ __device__ __forceinline__ void pool_bwd_x_body(const PoolArgs &A, const int blo
                 const float sgn = (CP && KPT % 2 == 0) ? -1.f : 1.f;  // the packed path accumulated -dx
 #pragma unroll
                 for (int v = 0; v < KPT; ++v) {
-#if defined(MKB_EXP_NO_FLUSH)
-                    if (A.P < 0) atomicAdd(row + u0 + v, sgn * dx0[t][v] + dx1[t][v]);
-#elif defined(MKB_EXP_WG_ATOMICS)
-                    __hip_atomic_fetch_add(row + u0 + v, sgn * dx0[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if constexpr (CP) __hip_atomic_fetch_add(row + A.d + u0 + v, sgn * dx1[t][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
                     atomicAdd(row + u0 + v, sgn * dx0[t][v]);
                     if constexpr (CP) atomicAdd(row + A.d + u0 + v, sgn * dx1[t][v]);
-#endif
                 }
             }
         }
