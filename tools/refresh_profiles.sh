@@ -23,6 +23,7 @@ for c in wn18rr-rotate fb15k237-complex fb15k237-transe fb15k237-distmult yago31
   python bench.py --config $c --no-cpu-baseline --mrr-epochs 0 2>/dev/null | tail -1 >> $O/bench_configs.jsonl
 done
 for n in 1 2 4 8; do echo "world=$n $(python tools/shard_emulate.py $n 2>/dev/null | tail -1)" >> $O/shard_emulate.txt; done
+[ -x tools/ubench/valu_chain ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o tools/ubench/valu_chain tools/ubench/valu_chain.hip
 tools/ubench/valu_chain > $O/valu_ubench.txt 2>&1
 rm -rf $O/ktrace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq   # keep the summaries, not the databases
 ls -la $O
