@@ -444,3 +444,26 @@ def test_foreign_negatives_are_scanned_for_their_shared_pool(name, monkeypatch):
     np.testing.assert_allclose(got[True][0], got[False][0], rtol=0, atol=ATOL)
     np.testing.assert_allclose(got[True][1], got[False][1], rtol=0, atol=1e-5)
     np.testing.assert_allclose(got[True][2], got[False][2], rtol=1e-4, atol=1e-5)
+
+
+def test_diverse_foreign_negatives_stay_on_the_general_kernels():
+    """Negatives that draw on more than 2K distinct entities have no shared pool: the scan says so and the general
+    kernels score them (same result as with the scan switched off)."""
+    from mkb_amd import datasets, models
+    from mkb_amd.sampling.negative_sampling import PoolInfo
+    import mkb_amd.models.base as model_base
+
+    ds = datasets.Fb15k237(batch_size=512, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(1)
+    m = models.TransE(hidden_dim=64, entities=ds.entities, relations=ds.relations, gamma=9.0).cuda()
+    s = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)[:512]).cuda()
+    neg = torch.randint(0, len(ds.entities), (512, 64), generator=torch.Generator().manual_seed(3)).cuda()
+    assert PoolInfo.discover(neg, s, 2) is None
+    with torch.no_grad():
+        a = m(s, neg, "tail-batch")
+        model_base.AUTO_POOL = False
+        try:
+            b = m(s, neg, "tail-batch")
+        finally:
+            model_base.AUTO_POOL = True
+    assert torch.equal(a, b)
