@@ -167,3 +167,39 @@ class Adam:
                 else:
                     p.grad.zero_()
         self._zeroed = False
+
+    # ------------------------------------------------------------------ checkpointing (torch.optim-style)
+    def state_dict(self):
+        """Like ``torch.optim.Adam.state_dict()``: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` (clones) keyed by
+        the parameter's position, plus the hyper-parameters.  Pending row-lazy steps are flushed first, so the tables and
+        the moments the caller saves next to each other are the dense-Adam state of this step."""
+        self.flush()
+        state = {}
+        for i, p in enumerate(self.params):
+            st = self.state.get(p)
+            if st is not None:
+                state[i] = {"step": st["n"], "exp_avg": st["m"].clone(), "exp_avg_sq": st["v"].clone()}
+        return {"state": state, "param_groups": [{"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                                                  "params": list(range(len(self.params)))}],
+                "step_count": self.step_count}
+
+    def load_state_dict(self, sd):
+        """Restore ``state_dict()`` onto an optimizer built over the same parameters (their tables must be restored by the
+        caller, e.g. ``model.load_state_dict``): every row is then current through the saved step."""
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.step_count = sd.get("step_count", 0)
+        for i, p in enumerate(self.params):
+            saved = sd["state"].get(i, sd["state"].get(str(i)))
+            if saved is None:
+                self.state.pop(p, None)
+                continue
+            st = self._state(p)
+            st["m"].copy_(saved["exp_avg"])
+            st["v"].copy_(saved["exp_avg_sq"])
+            st["n"] = int(saved["step"])
+            st.pop("caught_up", None)
+            st["flushed"] = st["n"]
+            if "last" in st:  # row-lazy: nothing is pending, the replay constants of earlier steps are not needed again
+                st["last"].fill_(st["n"])
+        self._zeroed = False

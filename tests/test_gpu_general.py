@@ -208,3 +208,52 @@ def test_sampler_emits_touched_rows_and_adam_rider_equals_separate_launches():
         ref.step()
     np.testing.assert_allclose(results[0][0], ent.detach().cpu().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(results[0][1], rel.detach().cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_optimizer_and_sampler_checkpoint_resume_is_exact():
+    """state_dict / load_state_dict of mkb_amd.optim.Adam (row-lazy and dense parameters) + the sampler's generator state:
+    a run resumed from a checkpoint continues bit-identically to the uninterrupted run."""
+    from mkb_amd import datasets, optim, sampling
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    mk_s = lambda: sampling.NegativeSampling(size=24, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9)
+
+    def make():
+        g = torch.Generator(device="cpu").manual_seed(1)
+        ent = torch.nn.Parameter(torch.randn(5000, 64, generator=g).cuda())  # row-lazy
+        rel = torch.nn.Parameter(torch.randn(46, 64, generator=g).cuda())    # dense
+        return ent, rel, optim.Adam([ent, rel], lr=1e-3, lazy_rows=True)
+
+    def run(ent, rel, opt, sam, steps):
+        for it in steps:
+            s = train[it * 61: it * 61 + 61].contiguous()
+            neg = sam.generate_with_catch_up(s, "head-batch" if it % 2 else "tail-batch", opt, ent)
+            ids = neg._mkb_pool.touched
+            ent.grad = torch.zeros_like(ent)
+            ent.grad[torch.unique(ids)] = 0.125 * (it + 1)
+            rel.grad = torch.full_like(rel, 0.25 * (it + 1))
+            ent._mkb_touched = ids
+            opt.step()
+            opt.zero_grad()
+
+    ent, rel, opt = make()
+    sam = mk_s()
+    run(ent, rel, opt, sam, range(4))
+    ckpt = {"ent": ent.detach().clone(), "rel": rel.detach().clone(), "opt": opt.state_dict(), "rng": sam.get_state()}
+    ckpt["ent"] = ent.detach().clone()  # (state_dict flushed the pending row-lazy steps into the table)
+    run(ent, rel, opt, sam, range(4, 8))
+    opt.flush()
+    want = (ent.detach().clone(), rel.detach().clone())
+
+    ent2, rel2, opt2 = make()
+    with torch.no_grad():
+        ent2.copy_(ckpt["ent"]); rel2.copy_(ckpt["rel"])
+    opt2.load_state_dict(ckpt["opt"])
+    sam2 = mk_s()
+    sam2.set_state(*ckpt["rng"], device=torch.device("cuda", 0))
+    run(ent2, rel2, opt2, sam2, range(4, 8))
+    opt2.flush()
+    assert torch.equal(ent2.detach(), want[0]) and torch.equal(rel2.detach(), want[1])
+    ka, pa = sam.get_state(); kb, pb = sam2.get_state()
+    assert pa == pb and np.array_equal(ka, kb)
