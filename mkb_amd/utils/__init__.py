@@ -1,5 +1,6 @@
 from .bar import Bar, BarRange
 from .io import read_csv, read_json
+from .predict import FetchToPredict, make_prediction
 from .stats import Mean, RollingMean
 
-__all__ = ["Bar", "BarRange", "Mean", "RollingMean", "read_csv", "read_json"]
+__all__ = ["Bar", "BarRange", "FetchToPredict", "Mean", "RollingMean", "make_prediction", "read_csv", "read_json"]

@@ -257,3 +257,16 @@ def test_optimizer_and_sampler_checkpoint_resume_is_exact():
     assert torch.equal(ent2.detach(), want[0]) and torch.equal(rel2.detach(), want[1])
     ka, pa = sam.get_state(); kb, pb = sam2.get_state()
     assert pa == pb and np.array_equal(ka, kb)
+
+
+def test_make_prediction_reference_doctest_known_answer():
+    """utils/predict.py:69-96: TransE hidden 3 on Umls (seed 42), scores of test[:3] -> tensor([-2.4270, -2.1356, -2.4053])."""
+    from mkb_amd import datasets, models, utils
+
+    torch.manual_seed(42)
+    dataset = datasets.Umls(batch_size=2)
+    model = models.TransE(entities=dataset.entities, relations=dataset.relations, hidden_dim=3, gamma=6).cuda()
+    got = utils.make_prediction(model=model, dataset=dataset.test[:3], batch_size=20, device="cuda")
+    np.testing.assert_allclose(got.cpu().numpy(), [-2.4270, -2.1356, -2.4053], rtol=0, atol=1e-4)
+    batches = list(utils.FetchToPredict(dataset=[(0, 0, 1), (1, 0, 2), (1, 1, 3)], batch_size=2))
+    assert [b.tolist() for b in batches] == [[[0, 0, 1], [1, 0, 2]], [[1, 1, 3]]]  # predict.py:27-31
