@@ -10,8 +10,6 @@ loss, a foreign sampler, classification mode) takes the reference's explicit seq
 still dispatches to the HIP kernels.  The optimizer is the user's (``torch.optim.Adam`` in the reference's
 README, or ``mkb_amd.optim.Adam``).
 """
-import collections
-
 import torch
 
 from ..fused import FusedTrainStep, pooled_supported
@@ -23,6 +21,29 @@ from ..utils import Bar, RollingMean
 __all__ = ["Pipeline"]
 
 
+_WATCHED = ("HITS@3", "HITS@1")  # a round only counts as "no improvement" when both fall (pipeline.py:272-299)
+
+
+class _Patience:
+    """Early-stopping bookkeeping for the watched split.  ``anchor`` is the score dict of the last round that was NOT
+    worse (the reference re-anchors on every such round, it does not keep the maximum); ``stale`` counts the rounds in a
+    row that fell below the anchor on every watched metric."""
+
+    def __init__(self, limit):
+        self.limit, self.anchor, self.stale = limit, None, 0
+
+    def observe(self, scores):
+        fell = self.anchor is not None and all(self.anchor[m] > scores[m] for m in _WATCHED)
+        if fell:
+            self.stale += 1
+        else:
+            self.stale, self.anchor = 0, scores
+
+    @property
+    def exhausted(self):
+        return self.stale == self.limit  # (limit 0 stops at the first evaluation, as the reference's == test does)
+
+
 class Pipeline:
     def __init__(self, epochs, eval_every=2000, early_stopping_rounds=3, device="cpu"):
         self.epochs = epochs
@@ -30,106 +51,90 @@ class Pipeline:
         self.early_stopping_rounds = early_stopping_rounds
         self.device = device
         self.metric_loss = RollingMean(1000)
-        self.round_without_improvement_valid = 0
-        self.round_without_improvement_test = 0
-        self.history_valid = collections.defaultdict(float)
-        self.history_test = collections.defaultdict(float)
         self.valid_scores = {}
         self.test_scores = {}
         self.fuse = True  # set False to force the unfused autograd sequence
 
-    def learn(self, model, dataset, sampling, optimizer, loss, evaluation=None):
-        fused = None
-        if (self.fuse and isinstance(model, BaseModel) and isinstance(sampling, NegativeSampling)
+    # ------------------------------------------------------------------ one epoch of steps (pipeline.py:206-244)
+    def _fused_step_for(self, model, dataset, sampling, optimizer, loss):
+        """``FusedTrainStep`` when model, sampler and loss are the mkb_amd ones on a ROCm device, else None."""
+        if not (self.fuse and isinstance(model, BaseModel) and isinstance(sampling, NegativeSampling)
                 and type(loss) is Adversarial and model.entity_embedding.is_cuda
                 and pooled_supported(model, dataset.batch_size, sampling.size)):
-            fused = FusedTrainStep(model, loss.alpha)
-            if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "draw_ahead", "x") is None:
-                optimizer.draw_ahead = sampling  # mkb_amd.optim.Adam: the next pool's draw rides the catch-up launch
+            return None
+        if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "draw_ahead", "x") is None:
+            optimizer.draw_ahead = sampling  # mkb_amd.optim.Adam: the next pool's draw rides the catch-up launch
+        return FusedTrainStep(model, loss.alpha)
 
+    def _run_epoch(self, epoch, fused, model, dataset, sampling, optimizer, loss):
         pending = []  # fused path: losses stay on the device until the bar refreshes (one D2H copy per 10 steps)
 
-        def flush():
+        def drain():
             if pending:
                 for v in torch.stack(pending).tolist():
                     self.metric_loss.update(v)
                 pending.clear()
 
+        bar = Bar(dataset=dataset, update_every=10)
+        for data in bar:
+            sample = data["sample"].to(self.device)
+            mode = data["mode"]
+            if mode == "classification":
+                raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
+            weight = data["weight"].to(self.device)
+            if fused is not None:
+                # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
+                error = fused.sampled(sample, weight, sampling, mode)
+            else:
+                score = model(sample)
+                negative_sample = sampling.generate(sample=sample, mode=mode)
+                negative_sample = negative_sample.to(self.device)
+                negative_score = model(sample=sample, negative_sample=negative_sample, mode=mode)
+                error = loss(score, negative_score, weight)
+                error.backward()
+            _ = optimizer.step()
+            optimizer.zero_grad()
+            if fused is not None:
+                # the reference syncs on error.item() every step (pipeline.py:242); the rolling mean only has to be
+                # current when it is shown, so the same values are fed to it in the same order, in batches
+                pending.append(error.detach())
+                if bar.due() or len(pending) >= 64:
+                    drain()
+            else:
+                self.metric_loss.update(error.item())
+            bar.set_description(f"Epoch: {epoch}, loss: {self.metric_loss.get():4f}")
+        drain()
+        if hasattr(sampling, "check"):
+            sampling.check()  # KeyError / empty-filter errors of this epoch's batches (lazy: no per-batch sync)
+
+    # ------------------------------------------------------------------ evaluation rounds (pipeline.py:246-321)
+    def _score_splits(self, evaluation, model, dataset):
+        """Entity + relation ranking metrics of every split the dataset holds, stored and printed."""
+        for attr, title, triples in (("valid_scores", "Validation:", dataset.valid), ("test_scores", "Test:", dataset.test)):
+            if triples:
+                scores = evaluation.eval(model=model, dataset=triples)
+                scores.update(evaluation.eval_relations(model=model, dataset=triples))
+                setattr(self, attr, scores)
+                self.print_metrics(description=title, metrics=scores)
+
+    def learn(self, model, dataset, sampling, optimizer, loss, evaluation=None):
+        fused = self._fused_step_for(model, dataset, sampling, optimizer, loss)
+        patience = _Patience(self.early_stopping_rounds)
         for epoch in range(self.epochs):
-            bar = Bar(dataset=dataset, update_every=10)
-            for data in bar:
-                sample = data["sample"].to(self.device)
-                mode = data["mode"]
-                if mode == "classification":
-                    raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
-                weight = data["weight"].to(self.device)
-                if fused is not None:
-                    # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
-                    error = fused.sampled(sample, weight, sampling, mode)
-                    negative_sample = fused.negative_sample
-                else:
-                    score = model(sample)
-                    negative_sample = sampling.generate(sample=sample, mode=mode)
-                    negative_sample = negative_sample.to(self.device)
-                    negative_score = model(sample=sample, negative_sample=negative_sample, mode=mode)
-                    error = loss(score, negative_score, weight)
-                    error.backward()
-                _ = optimizer.step()
-                optimizer.zero_grad()
-                if fused is not None:
-                    # the reference syncs on error.item() every step (pipeline.py:242); the rolling mean only has to be
-                    # current when it is shown, so the same values are fed to it in the same order, in batches
-                    pending.append(error.detach())
-                    if bar.due() or len(pending) >= 64:
-                        flush()
-                else:
-                    self.metric_loss.update(error.item())
-                bar.set_description(f"Epoch: {epoch}, loss: {self.metric_loss.get():4f}")
-            flush()
-
-            if hasattr(sampling, "check"):
-                sampling.check()  # KeyError / empty-filter errors of this epoch's batches (lazy: no per-batch sync)
-
-            if evaluation is not None:
-                if (epoch + 1) % self.eval_every == 0:
-                    print(f"\n Epoch: {epoch}.")
-                    if dataset.valid:
-                        self.valid_scores = evaluation.eval(model=model, dataset=dataset.valid)
-                        self.valid_scores.update(evaluation.eval_relations(model=model, dataset=dataset.valid))
-                        self.print_metrics(description="Validation:", metrics=self.valid_scores)
-                    if dataset.test:
-                        self.test_scores = evaluation.eval(model=model, dataset=dataset.test)
-                        self.test_scores.update(evaluation.eval_relations(model=model, dataset=dataset.test))
-                        self.print_metrics(description="Test:", metrics=self.test_scores)
-                        if (self.history_test["HITS@3"] > self.test_scores["HITS@3"]
-                                and self.history_test["HITS@1"] > self.test_scores["HITS@1"]):
-                            self.round_without_improvement_test += 1
-                        else:
-                            self.round_without_improvement_test = 0
-                            self.history_test = self.test_scores
-                    else:
-                        if (self.history_valid["HITS@3"] > self.valid_scores["HITS@3"]
-                                and self.history_valid["HITS@1"] > self.valid_scores["HITS@1"]):
-                            self.round_without_improvement_valid += 1
-                        else:
-                            self.round_without_improvement_valid = 0
-                            self.history_valid = self.valid_scores
-                    if (self.round_without_improvement_valid == self.early_stopping_rounds
-                            or self.round_without_improvement_test == self.early_stopping_rounds):
-                        print(f"\n Early stopping at epoch {epoch}.")
-                        self.print_metrics(description="Validation:", metrics=self.valid_scores)
-                        self.print_metrics(description="Test:", metrics=self.test_scores)
-                        return self
+            self._run_epoch(epoch, fused, model, dataset, sampling, optimizer, loss)
+            if evaluation is None or (epoch + 1) % self.eval_every != 0:
+                continue
+            print(f"\n Epoch: {epoch}.")
+            self._score_splits(evaluation, model, dataset)
+            patience.observe(self.test_scores if dataset.test else self.valid_scores)  # the test split leads when present
+            if patience.exhausted:
+                print(f"\n Early stopping at epoch {epoch}.")
+                self.print_metrics(description="Validation:", metrics=self.valid_scores)
+                self.print_metrics(description="Test:", metrics=self.test_scores)
+                return self
 
         print(f"\n Epoch: {epoch}. \n")
-        if dataset.valid:
-            self.valid_scores = evaluation.eval(model=model, dataset=dataset.valid)
-            self.valid_scores.update(evaluation.eval_relations(model=model, dataset=dataset.valid))
-            self.print_metrics(description="Validation:", metrics=self.valid_scores)
-        if dataset.test:
-            self.test_scores = evaluation.eval(model=model, dataset=dataset.test)
-            self.test_scores.update(evaluation.eval_relations(model=model, dataset=dataset.test))
-            self.print_metrics(description="Test:", metrics=self.test_scores)
+        self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
         return self
 
     @classmethod

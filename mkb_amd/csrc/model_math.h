@@ -141,6 +141,19 @@ __device__ __forceinline__ void pair_bwd_cmod2(f2 qr, f2 qi, f2 xr, f2 xi, float
     acc_i -= w * b;
 }
 
+// One evaluation of the pair term feeds BOTH gradients (single-pass backward kernel): dq accumulates -g*u, dx +g*u.
+// 9 packed ops + 2 v_rsq per two complex dims (two separate passes cost 2 x (7 + 2)).
+__device__ __forceinline__ void pair_bwd_cmod2_both(f2 qr, f2 qi, f2 xr, f2 xi, float g, f2 &dq_r, f2 &dq_i, f2 &dx_r,
+                                                    f2 &dx_i) {
+    const f2 a = qr - xr, b = qi - xi;
+    const f2 n2 = __builtin_elementwise_fma(b, b, __builtin_elementwise_fma(a, a, f2{1e-30f, 1e-30f}));
+    const f2 w = f2{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)} * g;
+    dq_r = __builtin_elementwise_fma(-w, a, dq_r);
+    dq_i = __builtin_elementwise_fma(-w, b, dq_i);
+    dx_r = __builtin_elementwise_fma(w, a, dx_r);
+    dx_i = __builtin_elementwise_fma(w, b, dx_i);
+}
+
 // ---------------------------------------------------------------- query backward
 // Chain dq through build_q into the two fixed operands (a, b as in build_q_*).
 template <int MODEL, bool HEAD>

@@ -122,6 +122,17 @@ __global__ __launch_bounds__(kWGr) void all_fwd_kernel(AllArgs A) {
     }
 }
 
+// Position of the target in the reference's torch.argsort(score, descending=True) (evaluation.py:245-262).  Ties and NaN
+// need care: "1 + #{S[e] > S[target]}" alone ranks the target FIRST whenever nothing compares greater, i.e. for a collapsed
+// model (all scores equal) or a diverged one (NaN anywhere in the comparison) -- MRR = HITS@k = 1.0 for a broken run, which
+// the early-stopping logic of Pipeline.learn would then keep.  The order used here is the one of a stable descending sort
+// with torch's NaN convention: NaN sorts before every number, equal keys keep candidate order (lower entity id first).
+__device__ __forceinline__ bool ranks_before(float a, int64_t ia, float b, int64_t ib) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return an && (!bn || ia < ib);
+    return a > b || (a == b && ia < ib);
+}
+
 // one wave per query
 __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, const int64_t *__restrict__ sample, int B,
                                                    int64_t N, int64_t R, int head_mode,
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, 
     const float *row = S + (int64_t)i * N;
     const float st = row[target];
     int64_t cnt = 0;
-    for (int64_t e = lane; e < N; e += 64) cnt += row[e] > st ? 1 : 0;
+    for (int64_t e = lane; e < N; e += 64) cnt += ranks_before(row[e], e, st, target) ? 1 : 0;
     // other true triples (base.py:213-216 / 229-232): take back those that were counted
     const int64_t base = ((head_mode ? t : h) * R + r) * N;  // keys of this (fixed entity, relation) pair are contiguous
     int64_t lo = 0, hi = nk;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, 
         const int64_t key = keys[k];
         if (key >= base + N) break;
         const int64_t e = key - base;
-        if (e != target && row[e] > st) cnt -= 1;
+        if (e != target && ranks_before(row[e], e, st, target)) cnt -= 1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);

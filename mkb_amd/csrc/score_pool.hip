@@ -203,6 +203,12 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
         adversarial_finish_block(A.loss_rowpart, A.B, A.loss_scal, A.loss_out, red);
 }
 
+__global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restrict__ src, const uint16_t *__restrict__ cnt,
+                                                          float *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = cnt[i] ? src[i] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct Workspace {
     float *Q, *dQ, *G, *dpos, *scratch, *gemm_part;
@@ -267,8 +273,31 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const int min_x = (int)((B + 255) / 256);
     const int x_target = L.nw == 1 ? target / 2 : target;
     L.x_slices = clampi((x_target + pos_tiles - 1) / pos_tiles, min_x > 2 ? min_x : 2, 1 << 20);
+    // Single-pass backward (pool_bwd1_kernel; VALU models only): dims are cut into slices of 64 * kpt units, positions into
+    // blocks of <= 64 * halves (LDS accumulator <= 128 KB), row tiles into groups of 16 waves.  Position blocks are doubled
+    // until the grid holds ~4096 waves (16 per CU); each block costs one dQ partial buffer.
+    {
+        const char *e = getenv("MKB_POOL_BWD1");  // A/B switch: 0 = the two-pass merged kernel
+        L.bwd1 = (!L.mfma && !(e && e[0] == '0')) ? 1 : 0;
+        const int k1 = L.kpt >= 2 ? 2 : 1, nc = k1 * (cp ? 2 : 1);
+        const int lanes1 = (NU + k1 - 1) / k1;
+        L.dim_slices = (lanes1 + 63) / 64;
+        const int max_halves = 128 * 1024 / (64 * nc * 64 * 4);  // 2 at nc = 4, 4 at nc = 2, 8 at nc = 1
+        int npb = 1;
+        while (((P + npb - 1) / npb + 63) / 64 > max_halves) npb *= 2;
+        while (npb < kMaxSlices && (int64_t)row_tiles * L.dim_slices * npb < 4096 && (P + npb - 1) / npb > 32) npb *= 2;
+        if (const char *q = getenv("MKB_POOL_PBLOCKS")) { const int v = atoi(q); if (v >= npb && v <= kMaxSlices) npb = v; }
+        if (npb > kMaxSlices) L.bwd1 = 0;
+        if (L.bwd1) {
+            L.q_slices = npb;
+            L.pb_halves = (int)(((P + npb - 1) / npb + 63) / 64);
+            const int64_t waves = (int64_t)row_tiles * L.dim_slices * npb;
+            L.tiles_per_wave = (int)(waves >= 3 * 4096 ? waves / (2 * 4096) : 1);
+            if (const char *q = getenv("MKB_POOL_TPW")) { const int v = atoi(q); if (v >= 1 && v <= 64) L.tiles_per_wave = v; }
+        }
+    }
     if (const char *e = getenv("MKB_POOL_FSLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd_slices = v; }
-    if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma) L.q_slices = v; }
+    if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma && !L.bwd1) L.q_slices = v; }
     if (const char *e = getenv("MKB_POOL_XSLICES")) { const int v = atoi(e); if (v >= min_x && v >= 1) L.x_slices = v; }
     return true;
 }
@@ -416,7 +445,10 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
         A.g_modulus = gr->g_modulus;
         A.g_ent = gr->g_ent;
         static const bool split = getenv("MKB_POOL_SPLIT_BWD") != nullptr;  // A/B: the two passes as two launches
-        if (!split) {  // dq and dx passes in one grid (pool_bwd_kernel); profiled as the POOL_BWD_Q class
+        if (L.bwd1) {  // every pair term evaluated once (pool_bwd1_kernel); profiled as the POOL_BWD_Q class
+            ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+            if (int rc = launcher_of(tb->model)(4, head, L, A, st)) return rc;
+        } else if (!split) {  // dq and dx passes in one grid (pool_bwd_kernel); profiled as the POOL_BWD_Q class
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
             if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;
         } else {
@@ -487,7 +519,10 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
     RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, 1,
                tb->phase_div};
     if (int rc = dispatch_query_build(tb, mode_is_head(mode), ra, B, st)) return rc;
-    MKB_CHECK_HIP(hipMemcpyAsync(w.G, dpool_score, (size_t)B * 2 * K * 4, hipMemcpyDeviceToDevice, st));
+    // G = caller's gradient with the entries no row uses forced to 0 (the single-pass backward reads the mask off G)
+    hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((B * 2 * K + 255) / 256)), dim3(256), 0, st, dpool_score, cnt, w.G,
+                       B * 2 * K);
+    MKB_LAUNCH_CHECK();
     return pooled_bwd(tb, mode_is_head(mode), gr, sample, pool, cnt, B, 2 * K, w, L, st);
 }
 

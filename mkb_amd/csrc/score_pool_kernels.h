@@ -48,8 +48,9 @@ struct PoolArgs {
     float *g_ent;          // [N, De] table gradient (backward, x pass adds into it)
     float *g_modulus;      // pRotatE
     const float *modulus;  // pRotatE
-    int B, P, d, x_slices, q_slices;
+    int B, P, d, x_slices, q_slices;  // q_slices: dQ partial buffers (= position blocks of the single-pass backward)
     int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
+    int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 #ifdef MKB_TRACE_WG
@@ -634,16 +635,218 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_kernel(PoolArgs A) {
     else pool_bwd_q_body<MODEL, HEAD, KPT, NW>(A, b - A.x_blocks, lds_bwd);
 }
 
+// ------------------------------------------------------------------------------------------------ backward: single pass
+// pool_bwd1: every (row, pool position, unit) pair term is evaluated ONCE and feeds both gradients.
+//   workgroup = (dim slice of 64*KPT units, group of 16*tiles_per_wave row tiles, block of <= 64*halves pool positions;
+//                slot (h, l) of the block is position p = block + nblocks * (l * halves + h): blocks and halves are
+//                interleaved so that each gets the same share of the dense prefix p < K);
+//   wave      = one row tile at a time: q[8], dq[8] of its slice in registers.  Lane l holds the 8 gradient seeds and
+//               the entity id of slot (h, l) in VGPRs; per position they reach SGPRs with v_readlane (no LDS slab, no
+//               scalar-memory latency in the loop).  The 8 pair terms of a position update dq[r] and one running dx;
+//   dx        = accumulated in the workgroup's LDS array s_dx[slot][lane][component].  LDS float atomics are far too
+//               slow for this (ds_add_f32 ~ 128 cycles per wave instruction: measured 396 us for the launch), so the
+//               16 waves walk the block in 16 lock-step PHASES: in phase t wave w owns chunk (w + t) mod 16 (every
+//               16/halves-th lane of one half: equal shares of the dense prefix) and updates it with plain
+//               ds_read_b128 / ds_write_b128; one barrier per phase hands the chunks on;
+//   flush     = after the last phase the LDS array goes to the table gradient rows (one fp32 atomic per element and row
+//               group: 8 per element at the headline shape, as before); dq partial stored once per wave and block.
+// Nothing is recomputed: RotatE 9 packed ops + 2 v_rsq per two complex dims (the two-pass kernels: 14 + 4).
+constexpr int kBwd1Waves = 16;
+
+template <int NC> struct AccVec;
+template <> struct AccVec<1> { typedef float type; };
+template <> struct AccVec<2> { typedef float2 type; };
+template <> struct AccVec<4> { typedef float4 type; };
+
+template <int MODEL, bool HEAD, int KPT>
+__global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int NC = KPT * (CP ? 2 : 1);  // floats per lane and position
+    constexpr int NW = kBwd1Waves, WG = NW * 64;
+    typedef typename AccVec<NC>::type acc_t;
+    extern __shared__ __attribute__((aligned(16))) int lds1[];
+    const int halves = A.pb_halves, cap = halves * 64;  // halves in {1, 2, 4, 8}
+    acc_t *s_dx = reinterpret_cast<acc_t *>(lds1);                                                       // [cap][64]
+    unsigned long long *s_used = reinterpret_cast<unsigned long long *>(lds1 + (size_t)cap * NC * 64);  // [halves]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (scalar control flow)
+    int b = (int)blockIdx.x;
+    const int s = b % A.dim_slices; b /= A.dim_slices;
+    const int npb = A.q_slices, pb = b % npb, rg = b / npb;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = (s * 64 + lane) * KPT;
+    const int cph = NW / halves;  // chunks per half; chunk c = lanes l == c % cph (mod cph) of half c / cph
+    MKB_TRACE_T(tr_t0);
+
+    for (int e = tid * 4; e < cap * NC * 64; e += WG * 4)
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(s_dx) + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < halves) s_used[tid] = 0ull;
+    __syncthreads();
+    MKB_TRACE_T(tr_t1);
+
+    const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
+    const int row_tiles = (A.B + TI - 1) / TI;
+    for (int t = 0; t < A.tiles_per_wave; ++t) {
+        const int tile = (rg * A.tiles_per_wave + t) * NW + wave;
+        const bool have = tile < row_tiles;  // (wave-uniform; a wave without a tile only keeps the barriers)
+        const int i0 = tile * TI;
+        float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
+#pragma unroll
+        for (int r = 0; r < TI; ++r) {
+            if (have) load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) {
+                if (!have || i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+                dq0[r][v] = 0.f;
+                dq1[r][v] = 0.f;
+            }
+        }
+        float extra = 0.f;
+        int h_cur = -1;
+        float gv[TI];
+        int idv = 0;
+        unsigned long long mask_h = 0ull;
+        for (int ph = 0; ph < NW; ++ph) {
+            const int c = (wave + ph) & (NW - 1);
+            const int h = c / cph, l0 = c - h * cph;
+            if (have && h != h_cur) {  // a new half: this lane's slot is (h, lane)
+                h_cur = h;
+                const int p_own = pb + npb * (lane * halves + h);
+                const bool valid = p_own < A.P;
+                unsigned nz = 0;
+#pragma unroll
+                for (int r = 0; r < TI; ++r) {
+                    gv[r] = (valid && i0 + r < A.B) ? A.G[(int64_t)(i0 + r) * A.P + p_own] : 0.f;
+                    nz |= __float_as_uint(gv[r]) << 1;  // +-0 -> unused pair (the loss kernel writes 0 for them)
+                }
+                idv = valid ? (int)A.pool[p_own] : 0;
+                mask_h = __ballot(nz != 0);
+                if (lane == 0 && mask_h) atomicOr(&s_used[h], mask_h);
+            }
+            // lanes of this chunk: l0, l0 + cph, ...
+            unsigned long long cm = 0x1ull;  // bit pattern with every cph-th bit set
+            cm = cph == 1 ? ~0ull : cph == 2 ? 0x5555555555555555ull : cph == 4 ? 0x1111111111111111ull
+                 : cph == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+            unsigned long long rem = have ? (mask_h & (cm << l0)) : 0ull;
+            const int n = __popcll(rem);
+            if (n > 0) {
+                auto next_j = [&]() {  // next used slot of the chunk (scalar); past the end: repeats a harmless lane
+                    const int j = rem ? (int)__builtin_ctzll(rem) : 0;
+                    rem &= rem - 1ull;
+                    return j;
+                };
+                auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
+                    const float *x = A.ent + (int64_t)__builtin_amdgcn_readlane(idv, j) * A.De;
+                    load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
+                };
+                // One position ahead: the next candidate row's loads are issued before this position's 8 pair bodies
+                // (~500 cycles of VALU: more than an L2 hit).  A single loop body without unrolling keeps dq in place
+                // (an unrolled ring + branch-free variant, as in the two-pass kernels, spilled 30 VGPRs here).
+                float xn0[KPT], xn1[KPT];
+                int jn = next_j();
+                load_x(jn, xn0, xn1);
+                for (int it = 0; it < n; ++it) {
+                    const int j = jn;
+                    float x0[KPT], x1[KPT];
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) { x0[v] = xn0[v]; x1[v] = xn1[v]; }
+                    jn = next_j();
+                    load_x(jn, xn0, xn1);
+                    acc_t *slot = s_dx + (size_t)(h * 64 + j) * 64 + lane;
+                    float dx0[KPT], dx1[KPT];
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) { dx0[v] = 0.f; dx1[v] = 0.f; }
+#pragma unroll
+                    for (int r = 0; r < TI; ++r) {
+                        const float g = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r]), j));
+                        if ((__float_as_uint(g) << 1) != 0u) {  // wave-uniform: row r uses this position
+                            if constexpr (CP && KPT % 2 == 0) {
+#pragma unroll
+                                for (int v = 0; v < KPT; v += 2) {
+                                    f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
+                                    f2 br = f2{dx0[v], dx0[v + 1]}, bi = f2{dx1[v], dx1[v + 1]};
+                                    pair_bwd_cmod2_both(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
+                                                        f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]}, g, ar, ai, br, bi);
+                                    dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
+                                    dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
+                                    dx0[v] = br.x; dx0[v + 1] = br.y;
+                                    dx1[v] = bi.x; dx1[v + 1] = bi.y;
+                                }
+                            } else
+#pragma unroll
+                            for (int v = 0; v < KPT; ++v) {
+                                if constexpr (CP) {
+                                    Cplx dq, dx;
+                                    pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g, dq, dx);
+                                    dq0[r][v] += dq.re; dq1[r][v] += dq.im;
+                                    dx0[v] += dx.re; dx1[v] += dx.im;
+                                } else {
+                                    float dq, dx, e0 = 0.f;
+                                    pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g, A.kd, modulus, dq, dx, e0);
+                                    dq0[r][v] += dq;
+                                    dx0[v] += dx;
+                                    extra += g * e0;
+                                }
+                            }
+                        }
+                    }
+                    // this wave owns the chunk during the phase: plain read-modify-write (read late: 4 VGPRs less across the
+                    // rows).  Component order: [re/real KPT][im KPT]
+                    acc_t upd = *slot;
+                    if constexpr (NC == 1) upd += dx0[0];
+                    else if constexpr (NC == 2 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; }
+                    else if constexpr (NC == 2) { upd.x += dx0[0]; upd.y += dx1[0]; }
+                    else { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx1[0]; upd.w += dx1[1]; }
+                    *slot = upd;
+                }
+            }
+            __syncthreads();  // hand the chunks on
+        }
+        if (have) {
+            float *dQs = A.dQ + (int64_t)pb * A.B * A.De;
+#pragma unroll
+            for (int r = 0; r < TI; ++r)
+                if (i0 + r < A.B) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
+            if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
+                extra = wave_sum(extra);
+                if (lane == 0) atomicAdd(A.g_modulus, -extra);
+            }
+        }
+    }
+    MKB_TRACE_T(tr_t2);
+    // LDS accumulator -> table gradient rows (slots no row of the group used are skipped); the last phase ended with a barrier
+    for (int sidx = wave; sidx < cap; sidx += NW) {
+        const int h = sidx >> 6, l = sidx & 63;
+        if (!((s_used[h] >> l) & 1ull)) continue;
+        const int p = pb + npb * (l * halves + h);
+        if (u0 < NU) {
+            float *row = A.g_ent + A.pool[p] * A.De;
+            const acc_t a = s_dx[(size_t)sidx * 64 + lane];
+            if constexpr (NC == 1) atomicAdd(row + u0, a);
+            else if constexpr (NC == 2 && !CP) { atomicAdd(row + u0, a.x); atomicAdd(row + u0 + 1, a.y); }
+            else if constexpr (NC == 2) { atomicAdd(row + u0, a.x); atomicAdd(row + A.d + u0, a.y); }
+            else {
+                atomicAdd(row + u0, a.x); atomicAdd(row + u0 + 1, a.y);
+                atomicAdd(row + A.d + u0, a.z); atomicAdd(row + A.d + u0 + 1, a.w);
+            }
+        }
+    }
+    MKB_TRACE_OUT(A, 1, tr_t0, tr_t1, tr_t2, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ launch helpers
 struct PoolLaunch {
     int kpt, nw;          // units per lane, waves per workgroup (backward kernels)
     int fkpt, fnw;        // the same for the forward kernel (it amortises its wave reduction over more units per lane)
     int fwd_slices, q_slices, x_slices;
     int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
+    int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the three below
+    int dim_slices, pb_halves, tiles_per_wave;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
-typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd*/, bool head, const PoolLaunch &L, const PoolArgs &A,
                               hipStream_t st);
 int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
 int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
@@ -676,8 +879,29 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
     return MKB_OK;
 }
 
+template <int MODEL, bool HEAD, int KPT>
+static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+    constexpr int NC = KPT * (ModelTraits<MODEL>::cplx_pair ? 2 : 1);
+    const size_t lds = (size_t)L.pb_halves * 64 * NC * 64 * 4 + 64;
+    static size_t lds_ok = 0;  // per instantiation: opt in to more than 64 KB of dynamic LDS once
+    if (lds > 64 * 1024 && lds > lds_ok) {
+        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_ok = 160 * 1024;
+    }
+    PoolArgs A2 = A;
+    A2.q_slices = L.q_slices; A2.dim_slices = L.dim_slices; A2.pb_halves = L.pb_halves; A2.tiles_per_wave = L.tiles_per_wave;
+    const int row_tiles = (A.B + TI - 1) / TI, per_group = kBwd1Waves * L.tiles_per_wave;
+    const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);
+    hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT>), dim3(groups * L.q_slices * L.dim_slices),
+                       dim3(kBwd1Waves * 64), lds, st, A2);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
+    if (which == 4) return L0.kpt >= 2 ? launch_bwd1<MODEL, HEAD, 2>(L0, A, st) : launch_bwd1<MODEL, HEAD, 1>(L0, A, st);
     PoolLaunch L = L0;
     if (which == 0) { L.kpt = L0.fkpt; L.nw = L0.fnw; }
     if (L.kpt == 1 && L.nw == 1) return launch_cfg<MODEL, HEAD, 1, 1>(which, L, A, st);

@@ -1,17 +1,39 @@
-"""``Dataset`` -- the batch producer ``compose.Pipeline`` iterates (reference mkb/datasets/dataset.py:94-320).
+"""``Dataset`` -- the batch producer ``compose.Pipeline`` iterates.
 
-Same constructor, attributes and iteration order as the reference: two shuffled torch ``DataLoader`` s
-(head-batch and tail-batch views of the training triples) zipped and alternated; the torch RNG is seeded
-with ``seed`` at the end of construction (dataset.py:185-186) so the shuffle order is the reference's.
+Public contract of the reference class (mkb/datasets/dataset.py:94-335), built differently: the three splits live in one
+table that the label -> id relabelling maps over, the two training views (head-batch / tail-batch) come from a mode table,
+the endless ``next()`` streams are per-mode generators, and ``__repr__`` goes through the formatter shared with the other
+``mkb_amd`` objects.  What callers can observe is the reference's:
+
+* constructor arguments and public attributes (``train / valid / test``, ``entities``, ``relations``, ``n_entity``,
+  ``n_relation``, ``dataset_head``, ``dataset_tail``, ``len``, ``step`` ...);
+* iteration: the two shuffled ``DataLoader`` views advance in lock step, head-batch first (dataset.py:196-203), and stop
+  with the shorter one; ``next(dataset)`` alternates tail, head, tail ... without ever stopping (dataset.py:205-214);
+* the torch RNG is re-seeded with ``seed`` as the LAST act of construction (dataset.py:185-186), which is what fixes the
+  shuffle order of the first epoch;
+* ids for unlabelled inputs are handed out in order of first appearance: all heads of train+valid+test, then all tails
+  (dataset.py:322-335).
 """
-import copy
+import itertools
 
 import torch
 from torch.utils import data
 
+from ..utils.fmt import aligned_block
 from .base import TestDataset, TrainDataset
 
 __all__ = ["Dataset"]
+
+_SPLITS = ("train", "valid", "test")
+_VIEWS = ("head-batch", "tail-batch")  # order matters: an epoch starts with the head-batch view
+
+
+def _first_seen(labels):
+    """label -> id in order of first appearance."""
+    index = {}
+    for label in labels:
+        index.setdefault(label, len(index))
+    return index
 
 
 class Dataset:
@@ -20,95 +42,101 @@ class Dataset:
                  classification_test=None):
         if classification:
             raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
+        self.batch_size, self.shuffle, self.seed = batch_size, shuffle, seed
+        self.classification, self.pre_compute, self.num_workers = classification, pre_compute, num_workers
+        self.classification_valid, self.classification_test = classification_valid, classification_test
         self.train, self.valid, self.test = train, valid, test
-        self.batch_size, self.shuffle = batch_size, shuffle
-        self.classification, self.pre_compute = classification, pre_compute
-        self.num_workers, self.seed = num_workers, seed
 
-        if entities is None:  # dataset.py:140-152: label -> id in order of first appearance
+        self.entities = entities
+        if entities is None:
             self.entities = self.mapping_entities()
-            relabel = lambda ts: None if ts is None else [(self.entities[h], r, self.entities[t]) for h, r, t in ts]
-            self.train, self.valid, self.test = relabel(self.train), relabel(self.valid), relabel(self.test)
-        else:
-            self.entities = entities
+            self._map_splits(lambda h, r, t: (self.entities[h], r, self.entities[t]))
+        self.relations = relations
         if relations is None:
             self.relations = self.mapping_relations()
-            relabel = lambda ts: None if ts is None else [(h, self.relations[r], t) for h, r, t in ts]
-            self.train, self.valid, self.test = relabel(self.train), relabel(self.valid), relabel(self.test)
-        else:
-            self.relations = relations
+            self._map_splits(lambda h, r, t: (h, self.relations[r], t))
+        self.n_entity, self.n_relation = len(self.entities), len(self.relations)
 
-        self.n_entity = len(self.entities)
-        self.n_relation = len(self.relations)
-
+        self._loaders = {mode: self.get_train_loader(mode=mode) for mode in _VIEWS}
+        self.len = int(sum(len(loader.dataset) for loader in self._loaders.values()) / batch_size)
         self.step = 0
-        self.dataset_head = self.get_train_loader(mode="head-batch")
-        self.dataset_tail = self.get_train_loader(mode="tail-batch")
-        self.len = int((len(self.dataset_head.dataset) + len(self.dataset_tail.dataset)) / self.batch_size)
-        self.fetch_head = self.fetch(self.dataset_head)
-        self.fetch_tail = self.fetch(self.dataset_tail)
+        self._streams = {mode: self.fetch(loader) for mode, loader in self._loaders.items()}
 
-        self.classification_valid = classification_valid
-        self.classification_test = classification_test
+        if seed:  # 0 / None leave the global generator alone, like the reference
+            torch.manual_seed(seed)
 
-        if self.seed:
-            torch.manual_seed(self.seed)
-
-    def __iter__(self):
-        for head, tail in zip(self.dataset_head, self.dataset_tail):
-            yield head
-            yield tail
-
-    def __next__(self):
-        self.step += 1
-        return next(self.fetch_head) if self.step % 2 == 0 else next(self.fetch_tail)
-
-    @staticmethod
-    def fetch(dataloader):
-        while True:
-            yield from dataloader
-
-    def __len__(self):
-        return self.len
+    # ------------------------------------------------------------------ splits
+    def _map_splits(self, fn):
+        for name in _SPLITS:
+            triples = getattr(self, name)
+            if triples is not None:
+                setattr(self, name, [fn(*triple) for triple in triples])
 
     @property
     def true_triples(self):
-        out = copy.deepcopy(self.train)
-        if self.valid is not None:
-            out += self.valid
-        if self.test is not None:
-            out += self.test
-        return out
+        """train + valid + test as one fresh list (absent splits skipped)."""
+        return [triple for name in _SPLITS for triple in (getattr(self, name) or ())]
 
     @property
     def train_triples(self):
         return self.train
 
+    def mapping_entities(self):
+        known = self.true_triples
+        return _first_seen(itertools.chain((h for h, _, _ in known), (t for _, _, t in known)))
+
+    def mapping_relations(self):
+        return _first_seen(r for _, r, _ in self.true_triples)
+
+    # ------------------------------------------------------------------ training views
     @property
-    def name(self):
-        return self.__class__.__name__
+    def dataset_head(self):
+        return self._loaders["head-batch"]
 
     @property
-    def _repr_title(self):
-        return f"{self.name} dataset"
+    def dataset_tail(self):
+        return self._loaders["tail-batch"]
 
     @property
-    def _repr_content(self):
-        return {
-            "Batch size": f"{self.batch_size}",
-            "Entities": f"{self.n_entity}",
-            "Relations": f"{self.n_relation}",
-            "Shuffle": f"{self.shuffle}",
-            "Train triples": f"{len(self.train) if self.train else 0}",
-            "Validation triples": f"{len(self.valid) if self.valid else 0}",
-            "Test triples": f"{len(self.test) if self.test else 0}",
-        }
+    def fetch_head(self):
+        return self._streams["head-batch"]
 
-    def __repr__(self):
-        l_len = max(map(len, self._repr_content.keys()))
-        r_len = max(map(len, self._repr_content.values()))
-        return f"{self._repr_title}\n" + "\n".join(
-            k.rjust(l_len) + "  " + v.ljust(r_len) for k, v in self._repr_content.items())
+    @property
+    def fetch_tail(self):
+        return self._streams["tail-batch"]
+
+    def get_train_loader(self, mode):
+        view = TrainDataset(triples=self.train, entities=self.entities, relations=self.relations, mode=mode,
+                            pre_compute=self.pre_compute, seed=self.seed)
+        return data.DataLoader(view, batch_size=self.batch_size, shuffle=self.shuffle, num_workers=self.num_workers,
+                               collate_fn=TrainDataset.collate_fn)
+
+    def __iter__(self):
+        # zip() stops with the shorter view; chain.from_iterable flattens each (head, tail) pair in that order
+        return itertools.chain.from_iterable(zip(*(self._loaders[mode] for mode in _VIEWS)))
+
+    def __next__(self):
+        self.step += 1
+        return next(self._streams[_VIEWS[self.step % 2]])  # odd steps: tail-batch, even steps: head-batch
+
+    @staticmethod
+    def fetch(dataloader):
+        """Endless stream of batches: a new pass over ``dataloader`` starts whenever one ends."""
+        while True:
+            for batch in dataloader:
+                yield batch
+
+    def __len__(self):
+        return self.len
+
+    # ------------------------------------------------------------------ evaluation views
+    def _get_test_loader(self, triples, batch_size, mode):
+        view = TestDataset(triples=triples, true_triples=self.train + self.test + self.valid, entities=self.entities,
+                           relations=self.relations, mode=mode)
+        return data.DataLoader(view, batch_size=batch_size, num_workers=self.num_workers, collate_fn=TestDataset.collate_fn)
+
+    def test_stream(self, triples, batch_size):
+        return [self._get_test_loader(triples=triples, batch_size=batch_size, mode=mode) for mode in _VIEWS]
 
     def test_dataset(self, batch_size):
         return self.test_stream(triples=self.test, batch_size=batch_size)
@@ -116,28 +144,22 @@ class Dataset:
     def validation_dataset(self, batch_size):
         return self.test_stream(triples=self.valid, batch_size=batch_size)
 
-    def test_stream(self, triples, batch_size):
-        return [self._get_test_loader(triples, batch_size, "head-batch"),
-                self._get_test_loader(triples, batch_size, "tail-batch")]
+    # ------------------------------------------------------------------ display
+    @property
+    def name(self):
+        return type(self).__name__
 
-    def get_train_loader(self, mode):
-        dataset = TrainDataset(triples=self.train, entities=self.entities, relations=self.relations, mode=mode,
-                               pre_compute=self.pre_compute, seed=self.seed)
-        return data.DataLoader(dataset=dataset, batch_size=self.batch_size, shuffle=self.shuffle,
-                               num_workers=self.num_workers, collate_fn=TrainDataset.collate_fn)
+    @property
+    def _repr_title(self):
+        return f"{self.name} dataset"
 
-    def _get_test_loader(self, triples, batch_size, mode):
-        test_dataset = TestDataset(triples=triples, true_triples=self.train + self.test + self.valid,
-                                   entities=self.entities, relations=self.relations, mode=mode)
-        return data.DataLoader(dataset=test_dataset, batch_size=batch_size, num_workers=self.num_workers,
-                               collate_fn=TestDataset.collate_fn)
+    @property
+    def _repr_content(self):
+        sizes = {name: len(getattr(self, name) or ()) for name in _SPLITS}
+        rows = [("Batch size", self.batch_size), ("Entities", self.n_entity), ("Relations", self.n_relation),
+                ("Shuffle", self.shuffle), ("Train triples", sizes["train"]), ("Validation triples", sizes["valid"]),
+                ("Test triples", sizes["test"])]
+        return {label: str(value) for label, value in rows}
 
-    def mapping_entities(self):
-        """dataset.py:322-331: ids in order of first appearance over all heads of train+valid+test, then all
-        tails."""
-        tt = self.true_triples
-        return {e: i for i, e in enumerate(dict.fromkeys([h for h, _, _ in tt] + [t for _, _, t in tt]))}
-
-    def mapping_relations(self):
-        """dataset.py:333-335."""
-        return {r: i for i, r in enumerate(dict.fromkeys([r for _, r, _ in self.true_triples]))}
+    def __repr__(self):
+        return aligned_block(self._repr_title, self._repr_content)

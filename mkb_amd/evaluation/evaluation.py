@@ -130,8 +130,12 @@ class Evaluation:
             bias = torch.where(true & (cand != r), -1.0, 0.0)
             neg = torch.stack([h.expand_as(k), rel, t.expand_as(k)], dim=-1)  # [b, R, 3]
             score = model(neg.contiguous()) + bias
-            target = score.gather(1, r)
-            out.append(1 + (score > target).sum(dim=1))
+            # position in a stable descending sort with NaN first (see ranks_before in csrc/rank.hip): a collapsed or
+            # diverged model must not rank its targets first
+            key = torch.nan_to_num(score, nan=float("inf"), posinf=float("inf"))
+            target = key.gather(1, r)
+            before = (key > target) | ((key == target) & (cand < r))
+            out.append(1 + before.sum(dim=1))
         return torch.cat(out) if out else torch.empty(0, dtype=torch.int64, device=dev)
 
     def eval_relations(self, model, dataset):

@@ -10,7 +10,7 @@
 """
 import torch
 
-from . import _hip
+from . import _hip, _links
 from .sampling.negative_sampling import PoolInfo
 
 __all__ = ["FusedTrainStep", "pooled_forward", "pooled_supported"]
@@ -103,7 +103,7 @@ class FusedTrainStep:
         catch-up launch when the entity table steps row-lazily (``mkb_amd.optim.Adam(lazy_rows=True)``): no sampler
         launch, identical negatives.  The negatives of the call stay available as ``self.negative_sample``."""
         ent = self.model.entity_embedding
-        lazy = getattr(ent, "_mkb_lazy", None)
+        lazy = _links.owner(ent)
         sample = _hip.contiguous(sample, torch.int64)
         if lazy is not None and sampler.size <= 512 and sample.is_cuda:
             neg = sampler.generate_with_catch_up(sample, mode, lazy, ent)
@@ -131,13 +131,13 @@ class FusedTrainStep:
         ws = _workspace(m, B, K)
         gr = self._grad_buffers()
         ent = m.entity_embedding
-        lazy = getattr(ent, "_mkb_lazy", None)
+        lazy = _links.owner(ent)
         if lazy is not None:  # row-lazy Adam: the rows this step reads must be current before the forward pass
             ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
             done = lazy._state(ent).get("caught_up")
             if done is None or done[0] is not ids or done[1] != lazy._state(ent)["n"]:  # (sampled() already did it)
                 lazy.catch_up(ent, ids)
-            ent._mkb_touched = ids
+            _links.mark_touched(ent, ids)  # accumulates when several steps share one optimizer.step()
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
                                                 _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(weight_sum),

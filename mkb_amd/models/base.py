@@ -18,8 +18,9 @@ import pickle
 import torch
 import torch.nn as nn
 
-from .. import _hip
+from .. import _hip, _links
 from ..sampling.negative_sampling import PoolInfo
+from ..utils.fmt import aligned_block
 
 __all__ = ["BaseModel"]
 
@@ -79,10 +80,7 @@ class Base(nn.Module):
         return {}
 
     def __repr__(self):
-        l_len = max(map(len, self._repr_content.keys()))
-        r_len = max(map(len, self._repr_content.values()))
-        return f"{self._repr_title}\n" + "\n".join(
-            k.rjust(l_len) + "  " + v.ljust(r_len) for k, v in self._repr_content.items())
+        return aligned_block(self._repr_title, self._repr_content)
 
     def save(self, path):
         if hasattr(self, "sync_parameters"):
@@ -149,7 +147,7 @@ class BaseModel(Base):
         """Bring the tables up to date when a row-lazy optimizer (mkb_amd.optim.Adam(lazy_rows=True)) is attached;
         no-op otherwise.  Called before any read of the tables outside the fused training step."""
         for p in (self.entity_embedding, self.relation_embedding):
-            opt = getattr(p, "_mkb_lazy", None)
+            opt = _links.owner(p)
             if opt is not None:
                 opt.flush(p)
 

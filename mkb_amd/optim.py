@@ -17,7 +17,7 @@ step / ``model.embeddings`` / ``model.save`` flush automatically; flush by hand 
 """
 import torch
 
-from . import _hip
+from . import _hip, _links
 
 __all__ = ["Adam"]
 
@@ -37,14 +37,14 @@ class Adam:
         if lazy_rows:
             for p in self.params:
                 if p.dim() == 2 and p.shape[0] >= 4096:  # big tables only; small ones stay on the dense kernel
-                    p._mkb_lazy = self
+                    _links.attach(p, self)
 
     # ------------------------------------------------------------------ state
     def _state(self, p):
         st = self.state.get(p)
         if st is None:
             st = self.state[p] = {"m": torch.zeros_like(p), "v": torch.zeros_like(p), "n": 0}
-            if getattr(p, "_mkb_lazy", None) is self:
+            if _links.owner(p) is self:
                 st["last"] = torch.zeros(p.shape[0], dtype=torch.int32, device=p.device)
                 st["consts"] = torch.zeros((1 << 16, 2), dtype=torch.float32, device=p.device)
         return st
@@ -77,7 +77,7 @@ class Adam:
     def flush(self, p=None):
         """Replay every pending zero-gradient step: afterwards the tables equal what dense Adam would hold."""
         for q in ([p] if p is not None else self.params):
-            if getattr(q, "_mkb_lazy", None) is not self:
+            if _links.owner(q) is not self:
                 continue
             st = self._state(q)
             if st["n"] <= 0 or st.get("flushed") == st["n"]:
@@ -94,12 +94,11 @@ class Adam:
     def _rider(self):
         """The dense tensor that steps inside the row-lazy launch (one fewer kernel per step): the first dense,
         16-byte aligned float32 parameter with a gradient, when some table steps row-lazily this time."""
-        lazy = [p for p in self.params if p.grad is not None and getattr(p, "_mkb_lazy", None) is self
-                and getattr(p, "_mkb_touched", None) is not None]
+        lazy = [p for p in self.params if p.grad is not None and _links.owner(p) is self and _links.touched(p) is not None]
         if len(lazy) != 1:
             return None, None
         for q in self.params:
-            if (q.grad is not None and getattr(q, "_mkb_lazy", None) is not self and q.is_cuda and q.device == lazy[0].device
+            if (q.grad is not None and _links.owner(q) is not self and q.is_cuda and q.device == lazy[0].device
                     and q.dtype == torch.float32 and q.is_contiguous() and q.grad.is_contiguous() and q.numel() >= 4
                     and "last" not in self._state(q)):
                 st = self._state(q)
@@ -129,7 +128,7 @@ class Adam:
             g = p.grad
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
-            touched = getattr(p, "_mkb_touched", None) if getattr(p, "_mkb_lazy", None) is self else None
+            touched = _links.take_touched(p) if _links.owner(p) is self else None
             with torch.cuda.device(p.device):
                 if touched is not None:
                     st["n"] += 1
@@ -142,12 +141,11 @@ class Adam:
                                                       _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1],
                                                       _hip.ptr(ids), ids.numel(), st["n"], self.lr, self.betas[0],
                                                       self.betas[1], self.eps, rider, _hip.stream_ptr()), "mkb_adam_rows_step")
-                    p._mkb_touched = None
                 else:
                     if "last" in st:  # a step whose touched rows are unknown: fall back to dense for good
                         self.flush(p)
                         st.pop("last"), st.pop("consts")
-                        p._mkb_lazy = None
+                        _links.detach(p)
                     st["n"] += 1
                     _hip.check(lib.mkb_adam_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
                                                  p.numel(), st["n"], self.lr, self.betas[0], self.betas[1], self.eps, 1,

@@ -23,6 +23,8 @@ backend in tests/test_parallel_gloo.py.
 import torch
 import torch.distributed as dist
 
+from . import _links
+
 __all__ = ["DimShardedStep", "SparseGradExchange", "allreduce_touched_rows", "gather_dims", "shard_dims", "shard_rows"]
 
 
@@ -109,9 +111,9 @@ class SparseGradExchange:
         extras.extend(extra_scalars)
         self.last_rows_moved = allreduce_touched_rows(m.entity_embedding.grad, ids, extras, self.group,
                                                       equal_counts=self.equal_batches)
-        if getattr(m.entity_embedding, "_mkb_lazy", None) is not None:
+        if _links.owner(m.entity_embedding) is not None:
             # row-lazy Adam must step every row ANY rank touched: hand it the gathered id list
-            m.entity_embedding._mkb_touched = self.last_union
+            _links.mark_touched(m.entity_embedding, self.last_union, replace=True)
 
     @property
     def last_union(self):
@@ -178,7 +180,7 @@ def shard_dims(model, rank, world, device=None):
 def gather_dims(local, group=None):
     """Reassemble the full tables from every rank's dimension shard: (entity_embedding, relation_embedding)."""
     rank, world, _, _ = local._dim_shard
-    opt = getattr(local.entity_embedding, "_mkb_lazy", None)
+    opt = _links.owner(local.entity_embedding)
     if opt is not None:
         opt.flush(local.entity_embedding)
     outs = []
@@ -223,7 +225,7 @@ class DimShardedStep:
         """``step(sample, weight, sampler.generate(sample, mode), mode)`` with the sampler folded into the row-lazy
         optimizer's catch-up launch (see ``FusedTrainStep.sampled``); every rank draws the same negatives."""
         ent = self.model.entity_embedding
-        lazy = getattr(ent, "_mkb_lazy", None)
+        lazy = _links.owner(ent)
         sample = self._hip.contiguous(sample, torch.int64)
         if lazy is not None and sampler.size <= 512 and sample.is_cuda:
             neg = sampler.generate_with_catch_up(sample, mode, lazy, ent)
@@ -247,13 +249,13 @@ class DimShardedStep:
         gr = _hip.Grads(m.entity_embedding.grad.data_ptr(), m.relation_embedding.grad.data_ptr(),
                         m.modulus.grad.data_ptr() if m.name == "pRotatE" else None)
         ent = m.entity_embedding
-        lazy = getattr(ent, "_mkb_lazy", None)
+        lazy = _links.owner(ent)
         if lazy is not None:
             ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
             done = lazy._state(ent).get("caught_up")
             if done is None or done[0] is not ids or done[1] != lazy._state(ent)["n"]:  # (sampled() already did it)
                 lazy.catch_up(ent, ids)
-            ent._mkb_touched = ids
+            _links.mark_touched(ent, ids)
         lib, tb = _hip.lib(), m._tables()
         nmb = max(1, min(self.micro_batches, B // 8))
         bounds = [(B * i // nmb, B * (i + 1) // nmb) for i in range(nmb)]

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from mkb_amd import _links
+
 pytestmark = pytest.mark.gpu
 
 MODELS = ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"]
@@ -136,7 +138,7 @@ def test_row_lazy_adam_is_bitwise_dense_adam():
     pl = torch.nn.Parameter(p0.clone())
     od = optim.Adam([pd], lr=3e-3)
     ol = optim.Adam([pl], lr=3e-3, lazy_rows=True)
-    assert pl._mkb_lazy is ol
+    assert _links.owner(pl) is ol
     g = torch.Generator(device="cuda").manual_seed(1)
     for step in range(40):
         ids = torch.randint(0, 600 if step % 3 else N, (257,), device="cuda", generator=g)   # duplicates inside
@@ -146,7 +148,7 @@ def test_row_lazy_adam_is_bitwise_dense_adam():
         grad = torch.zeros(N, D, device="cuda")
         grad[ids] = torch.randn(ids.numel(), D, device="cuda", generator=g)
         pd.grad, pl.grad = grad.clone(), grad.clone()
-        pl._mkb_touched = ids
+        _links.mark_touched(pl, ids)
         od.step(); ol.step()
         assert float(pl.grad.abs().sum()) == 0.0
         if step == 17:
@@ -186,7 +188,7 @@ def test_sampler_emits_touched_rows_and_adam_rider_equals_separate_launches():
             ent.grad[ids] = torch.randn(300, 64, generator=g).cuda()
             rel.grad = torch.randn(37, 64, generator=g).cuda()
             opt.catch_up(ent, ids)
-            ent._mkb_touched = ids
+            _links.mark_touched(ent, ids)
             opt.step()
             opt.zero_grad()
             assert rel.grad.abs().max().item() == 0.0  # zero_grad is fused into both routes
@@ -233,7 +235,7 @@ def test_optimizer_and_sampler_checkpoint_resume_is_exact():
             ent.grad = torch.zeros_like(ent)
             ent.grad[torch.unique(ids)] = 0.125 * (it + 1)
             rel.grad = torch.full_like(rel, 0.25 * (it + 1))
-            ent._mkb_touched = ids
+            _links.mark_touched(ent, ids)
             opt.step()
             opt.zero_grad()
 

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from mkb_amd import _links
+
 pytestmark = pytest.mark.gpu
 
 
@@ -130,7 +132,7 @@ def test_pool_drawn_ahead_inside_the_optimizer_launch_is_bit_identical():
         ent.grad = torch.zeros_like(ent)
         ent.grad[ids] = 1.0
         opt.catch_up(ent, ids)
-        ent._mkb_touched = ids
+        _links.mark_touched(ent, ids)
         opt.step()  # (the catch_up above carried the next pool's draw once a step had been taken)
         ka, pa = plain.get_state()
         kb, pb = ahead.get_state()   # the state BEFORE the pool drawn ahead
@@ -174,7 +176,7 @@ def test_sampler_riding_the_catch_up_launch_is_bit_identical(size):
             ids = info.touched
             ent.grad = torch.zeros_like(ent)
             ent.grad[torch.unique(ids)] = 0.5
-            ent._mkb_touched = ids
+            _links.mark_touched(ent, ids)
             opt.step()
         opt.flush()
         sam.check()

@@ -297,26 +297,56 @@ def gen_eval():
         json.dump(res, f, indent=1)
 
 
+def headline_tables(n_entity=14541, n_relation=237, hidden=1000, gamma=9.0, seed=2024):
+    """Tables of the headline-shape slice fixture, drawn with numpy's legacy generator (bit-stable across numpy
+    versions and platforms) instead of torch's CPU RNG stream, so the test that re-creates them never depends on the
+    torch build: U(-(gamma + 2) / hidden, +(gamma + 2) / hidden) like models/base.py:81-100."""
+    rs = np.random.RandomState(seed)
+    r = (gamma + 2.0) / hidden
+    ent = rs.uniform(-r, r, size=(n_entity, 2 * hidden)).astype(np.float32)
+    rel = rs.uniform(-r, r, size=(n_relation, hidden)).astype(np.float32)
+    return ent, rel
+
+
 def gen_headline_slice():
-    """One real-shape RotatE batch row-slice on FB15k-237 (hidden=1000, K=256) -- scores + loss only for a
-    16-row slice (the full 1024-row reference step takes ~80 s on CPU; the slice keeps the fixture small)."""
+    """One real-shape RotatE batch row-slice on FB15k-237 (hidden=1000, K=256): scores, loss AND gradients of a 16-row
+    slice from the live reference (the full 1024-row reference step takes ~80 s on CPU; the slice keeps the fixture
+    small).  The dense entity gradient (116 MB) is stored as: ids of its non-zero rows, every 8th column of those rows,
+    and their float64 row sums / squared norms; the relation gradient's non-zero rows are stored whole."""
     ds = datasets.Fb15k237(batch_size=16, shuffle=False, seed=42, num_workers=0)
-    torch.manual_seed(42)
     m = models.RotatE(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9)
+    ent, rel = headline_tables()
+    with torch.no_grad():
+        m.entity_embedding.copy_(torch.from_numpy(ent))
+        m.relation_embedding.copy_(torch.from_numpy(rel))
     ns = sampling.NegativeSampling(size=256, train_triples=ds.train, entities=ds.entities,
                                    relations=ds.relations, seed=42)
     train = np.asarray(ds.train)
-    idx = np.random.RandomState(7).randint(len(train), size=16)
+    rs = np.random.RandomState(7)
+    idx = rs.randint(len(train), size=16)
+    weight = (rs.rand(16) + 0.1).astype(np.float32)
     s = torch.LongTensor(train[idx])
-    out = {"idx": idx.astype(np.int32)}
-    # the 116 MB table is NOT stored: tests re-create it with the same torch CPU RNG calls and check these pins
-    out["ent_rows_pin"] = npy(m.entity_embedding[[0, 7270, 14540]])
-    out["rel_rows_pin"] = npy(m.relation_embedding[[0, 236]])
+    out = {"idx": idx.astype(np.int32), "weight": weight, "alpha": np.float32(1.0),
+           "table_seed": np.int32(2024)}
     for mode in ["head-batch", "tail-batch"]:
         neg = ns.generate(s, mode=mode)
+        m.zero_grad()
+        pos_score, neg_score = m(s), m(s, neg, mode)
+        err = losses.Adversarial(alpha=1.0)(pos_score, neg_score, torch.from_numpy(weight))
+        err.backward()
         out[f"{mode}/neg"] = npy(neg).astype(np.int32)
-        out[f"{mode}/score"] = npy(m(s, neg, mode))
-    out["pos"] = npy(m(s))
+        out[f"{mode}/score"] = npy(neg_score)
+        out[f"{mode}/pos"] = npy(pos_score)
+        out[f"{mode}/loss"] = npy(err)
+        ge, gr = npy(m.entity_embedding.grad), npy(m.relation_embedding.grad)
+        rows = np.flatnonzero(np.abs(ge).sum(1) > 0)
+        out[f"{mode}/g_ent_rows"] = rows.astype(np.int32)
+        out[f"{mode}/g_ent_cols8"] = ge[rows][:, ::8].copy()
+        out[f"{mode}/g_ent_rowsum"] = ge[rows].astype(np.float64).sum(1)
+        out[f"{mode}/g_ent_rowsq"] = (ge[rows].astype(np.float64) ** 2).sum(1)
+        rrows = np.flatnonzero(np.abs(gr).sum(1) > 0)
+        out[f"{mode}/g_rel_rows"] = rrows.astype(np.int32)
+        out[f"{mode}/g_rel"] = gr[rrows].copy()
     np.savez_compressed(OUT / "headline_slice.npz", **out)
 
 
