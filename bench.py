@@ -37,6 +37,8 @@ if ROOT not in sys.path:
 HIDDEN, K, B, GAMMA, ALPHA, LR = 1000, 256, 1024, 9.0, 1.0, 5e-5
 MODEL, DATASET = "RotatE", "fb15k237"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
+TRANS_PEAK_TOPS = 19.66   # quarter-rate transcendentals: 1024 SIMDs x 8 results/clk x 2.4 GHz
 
 # BASELINE.json configs; the default (and the only one the driver runs) is the headline, configs[2]
 CONFIGS = {
@@ -152,10 +154,15 @@ def train_and_rank(ctx, epochs, first_step):
                     "literature RotatE on FB15k-237 reaches MRR ~0.34 after long training"}
 
 
-def cpu_baseline(rows=64, seed=42):
-    """The oracle (torch-CPU restatement of the reference path, reference-faithful stack->norm RotatE forward)
-    timed on the host cores for ONE step on a bounded sample: `rows` rows of a headline batch, full tables,
-    same K / dims, sampler = the plain-C restatement, dense torch Adam over the full tables."""
+def cpu_baseline(rows=64, rows_sqrt=128, seed=42, warmup=1, timed=2):
+    """The oracle (torch-CPU restatement of the reference path) timed on the host cores, by BASELINE.md section 3's
+    protocol on a bounded sample: `warmup` untimed + `timed` timed steps over `rows` rows of a headline batch (full
+    tables, same K / dims), each phase timed on its own -- sample (the plain-C sampler restatement), fwd (positive +
+    negative forward), loss, bwd (autograd into dense gradients) -- and the dense torch-Adam step over the FULL tables
+    timed separately (it does not scale with the rows).  A 1024-row step is then
+        t_step = (t_sample + t_fwd + t_loss + t_bwd) * 1024 / rows + t_opt,     value = 1024 * (K + 1) / t_step.
+    Two forms of the RotatE forward: the reference-faithful stack -> norm(dim=0) (a torch-CPU pathology) and
+    sqrt(re^2 + im^2), so that the CPU figure is not inflated by that."""
     import ctypes
 
     from mkb_amd.datasets.base import subsampling_weights
@@ -171,34 +178,108 @@ def cpu_baseline(rows=64, seed=42):
     lib.orc_generate.restype = ctypes.c_int
     st = ctypes.create_string_buffer(4 * 624 + 4)
     lib.orc_mt_seed(st, ctypes.c_uint32(seed))
-    idx = np.random.RandomState(7).randint(len(train_np), size=rows)
-    smp = np.ascontiguousarray(train_np[idx])
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in (("ent", tb.ent), ("rel", tb.rel))}
     cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    neg = np.zeros((rows, K), dtype=np.int64)
-    pool = np.zeros(2 * K, dtype=np.int64)
-    rc = lib.orc_generate(st, ctypes.c_int64(n_ent), ctypes.c_int64(K), p(smp), ctypes.c_int64(rows), ctypes.c_int(1),
-                          p(hk), ctypes.c_int64(len(hk)), p(ho), p(hv), ctypes.c_int64(n_ent), p(neg), p(pool))
-    assert rc == 0
-    r = scoring.train_step_grads(tb, torch.as_tensor(smp), torch.as_tensor(neg), w_all[idx], "head-batch", ALPHA)
-    scoring.adam_update(tb.ent, r["g_ent"], *state["ent"], 1, lr=LR)
-    scoring.adam_update(tb.rel, r["g_rel"], *state["rel"], 1, lr=LR)
-    dt = time.perf_counter() - t0
-    # the reference's RotatE forward sits on a torch pathology (stack -> norm(dim=0)); the same step with
-    # the plain sqrt(re^2 + im^2) form is reported beside it so the CPU figure is not inflated by that
-    t1 = time.perf_counter()
-    r2 = scoring.train_step_grads(tb, torch.as_tensor(smp), torch.as_tensor(neg), w_all[idx], "head-batch", ALPHA,
-                                  fast_norm=True)
-    scoring.adam_update(tb.ent, r2["g_ent"], *state["ent"], 2, lr=LR)
-    scoring.adam_update(tb.rel, r2["g_rel"], *state["rel"], 2, lr=LR)
-    dt2 = time.perf_counter() - t1
-    return {"value": rows * (K + 1) / dt, "unit": "scored triples/s", "cores": cores, "kind": "port",
-            "value_sqrt_form": rows * (K + 1) / dt2,
-            "sample": f"1 step, {rows} of the 1024 rows of a headline batch (FB15k-237 RotatE hidden=1000 K=256, "
-                      f"full tables, reference-faithful stack->norm forward, C sampler, dense torch Adam): {dt:.1f} s; "
-                      f"value_sqrt_form = the same step with sqrt(re^2+im^2) instead of stack->norm: {dt2:.1f} s"}
+    pick = np.random.RandomState(7)
+
+    def one_step(n_rows, fast_norm):
+        """-> seconds per phase of one step over n_rows rows (head-batch)."""
+        idx = pick.randint(len(train_np), size=n_rows)
+        smp = np.ascontiguousarray(train_np[idx])
+        t = {}
+        t0 = time.perf_counter()
+        neg = np.zeros((n_rows, K), dtype=np.int64)
+        pool = np.zeros(2 * K, dtype=np.int64)
+        rc = lib.orc_generate(st, ctypes.c_int64(n_ent), ctypes.c_int64(K), p(smp), ctypes.c_int64(n_rows), ctypes.c_int(1),
+                              p(hk), ctypes.c_int64(len(hk)), p(ho), p(hv), ctypes.c_int64(n_ent), p(neg), p(pool))
+        assert rc == 0
+        t["sample"] = time.perf_counter() - t0
+        ent = tb.ent.detach().clone().requires_grad_(True)
+        rel = tb.rel.detach().clone().requires_grad_(True)
+        s_t, n_t, w_t = torch.as_tensor(smp), torch.as_tensor(neg), w_all[idx]
+        t0 = time.perf_counter()
+        pos = scoring.score(tb, s_t, ent=ent, rel=rel, fast_norm=fast_norm)
+        ngs = scoring.score(tb, s_t, n_t, "head-batch", ent=ent, rel=rel, fast_norm=fast_norm)
+        t["fwd"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        loss = scoring.adversarial(pos, ngs, w_t, ALPHA)
+        t["loss"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        loss.backward()
+        t["bwd"] = time.perf_counter() - t0
+        return t, ent.grad, rel.grad
+
+    def protocol(n_rows, fast_norm):
+        acc = {"sample": 0.0, "fwd": 0.0, "loss": 0.0, "bwd": 0.0}
+        g = None
+        for i in range(warmup + timed):
+            t, ge, gr = one_step(n_rows, fast_norm)
+            if i >= warmup:
+                for k in acc:
+                    acc[k] += t[k] / timed
+            g = (ge, gr)
+        return acc, g
+
+    split, grads = protocol(rows, False)
+    split_sqrt, _ = protocol(rows_sqrt, True)
+    # dense Adam over the full tables (zero_grad included), once warm + `timed` timed
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in (("ent", tb.ent), ("rel", tb.rel))}
+    t_opt = 0.0
+    for i in range(warmup + timed):
+        t0 = time.perf_counter()
+        scoring.adam_update(tb.ent, grads[0], *state["ent"], i + 1, lr=LR)
+        scoring.adam_update(tb.rel, grads[1], *state["rel"], i + 1, lr=LR)
+        grads[0].zero_(), grads[1].zero_()
+        if i >= warmup:
+            t_opt += (time.perf_counter() - t0) / timed
+    full = lambda sp, n: sum(sp.values()) * B / n + t_opt
+    ms = lambda sp: {k: round(v * 1e3, 2) for k, v in sp.items()}
+    return {"value": B * (K + 1) / full(split, rows), "unit": "scored triples/s", "cores": cores, "kind": "port",
+            "value_sqrt_form": B * (K + 1) / full(split_sqrt, rows_sqrt),
+            "ms_per_phase": dict(ms(split), opt_full_tables=round(t_opt * 1e3, 2), rows=rows),
+            "ms_per_phase_sqrt_form": dict(ms(split_sqrt), opt_full_tables=round(t_opt * 1e3, 2), rows=rows_sqrt),
+            "sample": f"{warmup} warm-up + {timed} timed steps over {rows} of the 1024 rows of a headline batch (FB15k-237 RotatE "
+                      f"hidden={HIDDEN} K={K}, full tables, reference-faithful stack->norm forward, C sampler), phases timed "
+                      f"separately; dense torch Adam over the full tables timed on its own; value = {B}*(K+1) / ((sample+fwd+loss+bwd)"
+                      f"*{B}/{rows} + opt); value_sqrt_form = the same protocol with sqrt(re^2+im^2) on {rows_sqrt} rows"}
+
+
+def step_variants(ctx, steps=60):
+    """the step with and without the optimizer / the sampler, outside the main timed region (N = 1).
+    'no_optimizer': sampler + forward + loss + backward into dense gradients that keep accumulating (no Adam, no zero_grad);
+    'no_sampler_no_optimizer': the same with ONE pre-drawn negative batch reused.  Scored triples/s each."""
+    from mkb_amd.fused import FusedTrainStep
+
+    m, sampler = ctx["model"], ctx["sampler"]
+    ctx["opt"].flush()
+    step = FusedTrainStep(m, ALPHA)
+    from mkb_amd import _links
+    owner = _links.owner(m.entity_embedding)
+    _links.detach(m.entity_embedding)  # plain dense-gradient path for these two loops
+    out = {}
+    try:
+        sample, weight = ctx["train"][:B], ctx["weights"][:B]
+        neg = sampler.generate(sample, "head-batch")
+        for name, draw in (("no_optimizer", True), ("no_sampler_no_optimizer", False)):
+            for i in range(5):
+                step(sample, weight, sampler.generate(sample, "head-batch") if draw else neg, "head-batch")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                lo = (i * B) % (ctx["n_train"] - B)
+                sm, wt = (ctx["train"][lo: lo + B], ctx["weights"][lo: lo + B]) if draw else (sample, weight)
+                mode = "head-batch" if (i % 2 == 0 or not draw) else "tail-batch"
+                step(sm, wt, sampler.generate(sm, mode) if draw else neg, mode)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            out[name] = {"value": B * (K + 1) / dt, "ms_per_step": dt * 1e3}
+    finally:
+        if owner is not None:
+            _links.attach(m.entity_embedding, owner)
+        for q in (m.entity_embedding, m.relation_embedding):
+            if q.grad is not None:
+                q.grad.zero_()
+    return out
 
 
 def main():
@@ -207,7 +288,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=128)
+    ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the cpu_baseline sample (reference-faithful form)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the with/without optimizer & sampler step variants")
     ap.add_argument("--profile-kernel", default="auto", help="kernel class bracketed with HIP events (or 'none')")
     ap.add_argument("--breakdown", action="store_true", help="also print per-phase timings (stderr)")
     ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "dims"), choices=["dims", "rows"],
@@ -333,42 +415,56 @@ def main():
     roof = None
     if launches:
         avg_s = kms / launches / 1e3
-        if prof_kind == "adam":
-            # one launch per parameter tensor; algorithmic bytes = 4 reads + 4 writes (p, m, v, g=0) of the tensor
-            n_el = (N * De + R * Dr) / 2.0  # average over the two launches per step
-            alg = 8 * 4 * n_el
-            what = "dense Adam (+zero_grad) kernel: 8 x 4 B per parameter element, averaged over the ent/rel launches"
-        else:
-            # logical gather/scatter bytes of the reference formulation, per pass over the negatives:
-            # every scored slot reads its entity row (fwd) / re-reads it and adds one gradient row (bwd)
-            passes = 2 if (prof_kind == "pool_bwd_q" and merged_bwd) else 1
-            alg = passes * Bk * K * De * 4
-            label = "pool_bwd (dq + dx passes, one launch)" if passes == 2 else prof_kind
-            what = (f"{label} kernel: logical bytes of the reference formulation (B*K entity rows of {De * 4} B "
-                    f"gathered / re-read / scattered once per pass, {passes} pass(es) in this launch); the kernel itself is "
-                    f"VALU-bound (transcendental rate, DESIGN.md section 5) and reuses each pool row from registers, so "
-                    f"the logical rate may exceed the HBM peak")
-        ach = alg / avg_s / 1e9
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/traffic.json)
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 traffic = json.load(f).get(prof_kind, {}).get("hbm_bytes_per_launch")
         except OSError:
             pass
-        roof = {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
-                "algorithmic_bytes_per_launch": alg, "note": what}
-        if MODEL == "RotatE" and prof_kind in ("pool_fwd", "pool_bwd_q", "pool_bwd_x"):
-            # the bound that actually binds: SIMD time of the packed pair bodies measured by
-            # tools/ubench/valu_chain.hip (profiles/r01_valu_ubench.txt) x the bodies this launch evaluates
+        if prof_kind == "adam":
+            # one launch per parameter tensor; algorithmic bytes = 4 reads + 4 writes (p, m, v, g=0) of the tensor
+            n_el = (N * De + R * Dr) / 2.0  # average over the two launches per step
+            alg = 8 * 4 * n_el
+            ach = alg / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
+                    "note": "dense Adam (+zero_grad) kernel: 8 x 4 B per parameter element, averaged over the ent/rel launches"}
+        else:
+            # The pooled kernels reuse every candidate row from registers / L2 (PMC traffic is ~1/30 of the logical gather
+            # bytes), so HBM does not bound them: the fp32 VALU + the quarter-rate transcendental pipe do.
+            # achieved = ALGORITHMIC flop per launch (every used (row, pool position, dim) pair term evaluated ONCE; flop per
+            # term from the instruction sequence in model_math.h) / mean launch duration, against the 157.3 TFLOP/s fp32
+            # vector peak of MI355X_MICROARCH.md.  The MFMA route of the bilinear models is priced as its three GEMMs.
             info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
-            pairs = int((info.cnt.to(torch.int32) > 0).sum().item())  # (row, pool position) pairs actually evaluated
-            body_ns = 15.9 if prof_kind == "pool_fwd" else 19.6
-            n_pass = 2 if (prof_kind == "pool_bwd_q" and merged_bwd) else 1
-            floor_us = n_pass * pairs * (m_.hidden_dim / 128.0) / 1024.0 * body_ns * 1e-3
-            roof.update({"valu_floor_us": floor_us, "valu_frac": floor_us / (avg_s * 1e6),
-                         "valu_note": f"{n_pass} pass(es) x {pairs} (row, pool position) pairs x {m_.hidden_dim} complex dims "
-                                      f"/ 128 per wave-body / 1024 SIMDs x {body_ns} ns per body (micro-benchmark of the body alone)"})
+            pairs = int((info.cnt.to(torch.int32) > 0).sum().item())  # (row, pool position) pairs the batch really uses
+            units = m_.hidden_dim if MODEL == "RotatE" else De       # pair terms per (row, position)
+            bwd = prof_kind != "pool_fwd"
+            # flop / transcendentals per pair term (one complex dim for RotatE, one float otherwise)
+            per_term = {"RotatE": ((6, 1), (15, 1)), "TransE": ((2, 0), (4, 0)), "pRotatE": ((4, 1), (9, 2)),
+                        "ComplEx": ((2, 0), (4, 0)), "DistMult": ((2, 0), (4, 0))}[MODEL][1 if bwd else 0]
+            mfma = MODEL in ("ComplEx", "DistMult")
+            if mfma:  # S = Q.X^T | dQ = G.X | dX = G^T.Q over the whole [B, P] block
+                flop = 2.0 * Bk * (2 * K) * De
+                trans = 0.0
+            else:
+                flop = float(pairs) * units * per_term[0]
+                trans = float(pairs) * units * per_term[1]
+            ach = flop / avg_s / 1e12
+            label = "pool_bwd (single pass: dq and dx from one evaluation of every pair term)" if bwd else "pool_fwd"
+            roof = {"bound": "mfma" if mfma else "valu", "kernel": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6,
+                    "launches": launches, "algorithmic_flop_per_launch": flop,
+                    "note": f"{label}: {pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop"
+                            + (" (MFMA GEMM: 2*B*P*De)" if mfma else "") + "; peak = fp32 vector / matrix rate of MI355X"}
+            if trans:
+                t_rate = trans / avg_s / 1e12
+                roof.update({"transcendental_rate_Tops": t_rate, "transcendental_peak_Tops": TRANS_PEAK_TOPS,
+                             "transcendental_frac": t_rate / TRANS_PEAK_TOPS,
+                             # issue-slot view: packed fp32 ops take 4 cycles per wave for 2 x 64 results, v_rsq / v_sqrt 8 for 64
+                             "issue_frac": (flop / 2.0 / 32.0 + trans / 8.0) / (1024 * 2.4e9) / avg_s})
+            # secondary: SURVEY 8(d)'s logical gather bytes (what the reference formulation would move) -- a REUSE figure, may
+            # exceed the HBM peak; never a roofline fraction
+            roof["logical_gather_GBps"] = (2 if bwd else 1) * Bk * K * De * 4 / avg_s / 1e9
     out = {
         "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
         else f"scored triples/sec (pos+K neg), {args.config}", "value": value, "unit": "triples/s",
@@ -388,6 +484,8 @@ def main():
     }
     if world == 1 and args.mrr_epochs > 0:
         out["mrr"] = train_and_rank(ctx, args.mrr_epochs, args.warmup + 8 + args.steps)
+    if world == 1 and args.config == "headline" and not args.no_variants:
+        out["step_variants"] = step_variants(ctx)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(rows=args.cpu_rows)
     print(json.dumps(out))

@@ -12,6 +12,7 @@ README, or ``mkb_amd.optim.Adam``).
 """
 import torch
 
+from ..datasets.device import DeviceBatches
 from ..fused import FusedTrainStep, pooled_supported
 from ..losses import Adversarial
 from ..models.base import BaseModel
@@ -54,6 +55,10 @@ class Pipeline:
         self.valid_scores = {}
         self.test_scores = {}
         self.fuse = True  # set False to force the unfused autograd sequence
+        # Opt-in: iterate ``datasets.DeviceBatches`` (training triples + weights resident in HBM, batches index-selected on
+        # the device) instead of the dataset's two host DataLoaders.  Same batch format, alternation and coverage; the
+        # shuffle ORDER is a seeded device randperm, not the reference's CPU RandomSampler order, hence not the default.
+        self.device_batches = False
 
     # ------------------------------------------------------------------ one epoch of steps (pipeline.py:206-244)
     def _fused_step_for(self, model, dataset, sampling, optimizer, loss):
@@ -75,13 +80,16 @@ class Pipeline:
                     self.metric_loss.update(v)
                 pending.clear()
 
+        # the fused step runs where the model lives (a script that keeps the reference's default device="cpu" but moved the
+        # model to the GPU still works); the explicit sequence follows the reference and uses self.device
+        device = model.entity_embedding.device if fused is not None else self.device
         bar = Bar(dataset=dataset, update_every=10)
         for data in bar:
-            sample = data["sample"].to(self.device)
+            sample = data["sample"].to(device)
             mode = data["mode"]
             if mode == "classification":
                 raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
-            weight = data["weight"].to(self.device)
+            weight = data["weight"].to(device)
             if fused is not None:
                 # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
                 error = fused.sampled(sample, weight, sampling, mode)
@@ -118,6 +126,8 @@ class Pipeline:
                 self.print_metrics(description=title, metrics=scores)
 
     def learn(self, model, dataset, sampling, optimizer, loss, evaluation=None):
+        if self.device_batches and not isinstance(dataset, DeviceBatches):
+            dataset = DeviceBatches(dataset, device=self.device, seed=getattr(dataset, "seed", None) or 42)
         fused = self._fused_step_for(model, dataset, sampling, optimizer, loss)
         patience = _Patience(self.early_stopping_rounds)
         for epoch in range(self.epochs):

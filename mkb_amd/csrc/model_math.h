@@ -154,6 +154,29 @@ __device__ __forceinline__ void pair_bwd_cmod2_both(f2 qr, f2 qi, f2 xr, f2 xi, 
     dx_i = __builtin_elementwise_fma(w, b, dx_i);
 }
 
+// Two rows against the same candidate, written stage by stage so that the two dependent chains (sub -> fma -> fma -> rsq ->
+// mul -> fma) interleave: a lone chain leaves an idle issue slot after most of its packed ops (the compiler pads them
+// with s_nop), two chains fill each other's slots.
+__device__ __forceinline__ void pair_bwd_cmod2_both_x2(f2 qrA, f2 qiA, f2 qrB, f2 qiB, f2 xr, f2 xi, float gA, float gB,
+                                                       f2 &dqrA, f2 &dqiA, f2 &dqrB, f2 &dqiB, f2 &dx_r, f2 &dx_i) {
+    const f2 eps = f2{1e-30f, 1e-30f};
+    const f2 aA = qrA - xr, aB = qrB - xr, bA = qiA - xi, bB = qiB - xi;
+    f2 nA = __builtin_elementwise_fma(aA, aA, eps), nB = __builtin_elementwise_fma(aB, aB, eps);
+    nA = __builtin_elementwise_fma(bA, bA, nA);
+    nB = __builtin_elementwise_fma(bB, bB, nB);
+    const f2 rA = f2{__builtin_amdgcn_rsqf(nA.x), __builtin_amdgcn_rsqf(nA.y)};
+    const f2 rB = f2{__builtin_amdgcn_rsqf(nB.x), __builtin_amdgcn_rsqf(nB.y)};
+    const f2 wA = rA * gA, wB = rB * gB;
+    dqrA = __builtin_elementwise_fma(-wA, aA, dqrA);
+    dqrB = __builtin_elementwise_fma(-wB, aB, dqrB);
+    dqiA = __builtin_elementwise_fma(-wA, bA, dqiA);
+    dqiB = __builtin_elementwise_fma(-wB, bB, dqiB);
+    dx_r = __builtin_elementwise_fma(wA, aA, dx_r);
+    dx_i = __builtin_elementwise_fma(wA, bA, dx_i);
+    dx_r = __builtin_elementwise_fma(wB, aB, dx_r);
+    dx_i = __builtin_elementwise_fma(wB, bB, dx_i);
+}
+
 // ---------------------------------------------------------------- query backward
 // Chain dq through build_q into the two fixed operands (a, b as in build_q_*).
 template <int MODEL, bool HEAD>

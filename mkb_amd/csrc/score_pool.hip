@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restric
 
 // ------------------------------------------------------------------------------------------------ host side
 struct Workspace {
-    float *Q, *dQ, *G, *dpos, *scratch, *gemm_part;
+    float *Q, *dQ, *G, *dpos, *scratch, *gemm_part, *dXp;
+    unsigned long long *xused;
     size_t bytes;
 };
 
@@ -279,6 +280,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     {
         const char *e = getenv("MKB_POOL_BWD1");  // A/B switch: 0 = the two-pass merged kernel
         L.bwd1 = (!L.mfma && !(e && e[0] == '0')) ? 1 : 0;
+        L.row_groups = 0; L.cplx = cp ? 1 : 0; L.pb_halves = 0; L.tiles_per_wave = 1;
         const int k1 = L.kpt >= 2 ? 2 : 1, nc = k1 * (cp ? 2 : 1);
         const int lanes1 = (NU + k1 - 1) / k1;
         L.dim_slices = (lanes1 + 63) / 64;
@@ -294,6 +296,8 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             const int64_t waves = (int64_t)row_tiles * L.dim_slices * npb;
             L.tiles_per_wave = (int)(waves >= 3 * 4096 ? waves / (2 * 4096) : 1);
             if (const char *q = getenv("MKB_POOL_TPW")) { const int v = atoi(q); if (v >= 1 && v <= 64) L.tiles_per_wave = v; }
+            L.row_groups = (row_tiles + 16 * L.tiles_per_wave - 1) / (16 * L.tiles_per_wave);
+            L.cplx = cp ? 1 : 0;
         }
     }
     if (const char *e = getenv("MKB_POOL_FSLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd_slices = v; }
@@ -313,6 +317,10 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.dpos = take((size_t)B * 4);
     w.scratch = take((size_t)(B + 1) * 4);
     w.gemm_part = take(L.mfma ? (size_t)8 * B * (P > De ? P : De) * 4 : 0);  // split-K partials of the MFMA path
+    // single-pass backward: dx partials per row group [groups][blocks][slots][dim slices][64 lanes][NC] + used-slot masks
+    const size_t nc = (size_t)(L.kpt >= 2 ? 2 : 1) * (L.cplx ? 2 : 1);
+    w.dXp = take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * L.pb_halves * 64 * L.dim_slices * 64 * nc * 4 : 0);
+    w.xused = (unsigned long long *)take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * 8 * 8 : 0);
     w.bytes = off;
     return w;
 }
@@ -329,6 +337,7 @@ static PoolArgs make_args(const mkb_tables_t *tb, const int64_t *pool, const uin
     A.ent = tb->ent; A.Q = w.Q; A.pool = pool; A.cnt = cnt; A.G = w.G; A.dQ = w.dQ;
     A.B = (int)B; A.P = (int)P; A.d = tb->hidden_dim; A.De = tb->entity_dim; A.kd = tb->phase_div;
     A.modulus = tb->modulus; A.x_slices = L.x_slices; A.q_slices = L.q_slices;
+    A.dXp = w.dXp; A.xused = w.xused;
     const bool g = tb->model == MKB_TRANSE || tb->model == MKB_ROTATE || tb->model == MKB_PROTATE;
     A.c0 = g ? tb->gamma : 0.f;
     A.c1 = g ? -1.f : 1.f;

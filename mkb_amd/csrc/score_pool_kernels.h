@@ -32,6 +32,7 @@ namespace mkb {
 
 constexpr int TI = 8;       // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
 constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions / rows in flight per lane)
+constexpr int kRing1 = 3;   // candidate rows in flight per lane in the single-pass backward
 constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8 rows / positions takes the branch-free body
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 1024; // pool positions supported by the LDS tile lists
@@ -51,6 +52,8 @@ struct PoolArgs {
     int B, P, d, x_slices, q_slices;  // q_slices: dQ partial buffers (= position blocks of the single-pass backward)
     int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
     int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
+    float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
+    unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 #ifdef MKB_TRACE_WG
@@ -70,9 +73,11 @@ struct PoolArgs {
         tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = wall_clock64();                                 \
         tr[4] = hw; tr[5] = xcc; tr[6] = (unsigned long long)(work); tr[7] = blockIdx.x;            \
     }
+#define MKB_TRACE_ONLY(...) __VA_ARGS__
 #else
 #define MKB_TRACE_T(var)
 #define MKB_TRACE_OUT(A, kind, t0, t1, t2, work)
+#define MKB_TRACE_ONLY(...)
 #endif
 
 // a value every lane of the wave holds identically -> scalar register
@@ -667,7 +672,8 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     extern __shared__ __attribute__((aligned(16))) int lds1[];
     const int halves = A.pb_halves, cap = halves * 64;  // halves in {1, 2, 4, 8}
     acc_t *s_dx = reinterpret_cast<acc_t *>(lds1);                                                       // [cap][64]
-    unsigned long long *s_used = reinterpret_cast<unsigned long long *>(lds1 + (size_t)cap * NC * 64);  // [halves]
+    unsigned long long *s_used = reinterpret_cast<unsigned long long *>(lds1 + (size_t)cap * NC * 64);  // [halves <= 8]
+    int *s_done = lds1 + (size_t)cap * NC * 64 + 16;  // [NW] phases finished by each wave (hand-off chain, see below)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (scalar control flow)
@@ -678,10 +684,12 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     const int u0 = (s * 64 + lane) * KPT;
     const int cph = NW / halves;  // chunks per half; chunk c = lanes l == c % cph (mod cph) of half c / cph
     MKB_TRACE_T(tr_t0);
+    MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
 
     for (int e = tid * 4; e < cap * NC * 64; e += WG * 4)
         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(s_dx) + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < halves) s_used[tid] = 0ull;
+    if (tid < NW) s_done[tid] = 0;
     __syncthreads();
     MKB_TRACE_T(tr_t1);
 
@@ -703,105 +711,186 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
             }
         }
         float extra = 0.f;
-        int h_cur = -1;
-        float gv[TI];
-        int idv = 0;
-        unsigned long long mask_h = 0ull;
-        for (int ph = 0; ph < NW; ++ph) {
-            const int c = (wave + ph) & (NW - 1);
-            const int h = c / cph, l0 = c - h * cph;
-            if (have && h != h_cur) {  // a new half: this lane's slot is (h, lane)
-                h_cur = h;
+        // lanes of chunk c of a half: l0, l0 + cph, ... (bit pattern with every cph-th bit set, shifted by l0)
+        const unsigned long long cm = cph == 1 ? ~0ull : cph == 2 ? 0x5555555555555555ull : cph == 4 ? 0x1111111111111111ull
+                                      : cph == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
+        // Hand-off between phases.  Chunk (v + g) mod 16 of wave v in (global) phase g was wave v + 1's chunk in phase g - 1,
+        // wave v + 2's before that, ...: wave v may enter phase g as soon as wave v + 1 has finished phase g - 1 (which, by
+        // the same rule, implies every earlier owner has).  So instead of a workgroup barrier per phase -- 16 drains per
+        // tile with the SIMDs running out of ready waves at each (PMC: waves parked 55 % of their lifetime, VALU busy 44 %)
+        // -- each wave publishes its finished-phase count in LDS and waits for its ONE predecessor only; the waves fall
+        // into a staggered pipeline.  LDS operations of a wave are performed in order, so the count lands after the data.
+        const int g0 = t * NW, pred = (wave + 1) & (NW - 1);
+        auto hand_on = [&](int finished) {
+            if (lane == 0) __hip_atomic_store(&s_done[wave], have ? finished : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!have) return;
+            MKB_TRACE_ONLY(const unsigned long long th0 = __builtin_readcyclecounter();)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done[pred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < finished)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            MKB_TRACE_ONLY(tr_hand += __builtin_readcyclecounter() - th0;)
+        };
+        // The 16 phases of a tile split into RUNS of consecutive phases whose chunks lie in the same half (the seeds and ids
+        // of one half fit the lanes).  Inside a run the wave's used positions form one stream, ordered by phase: everything
+        // the loop needs per position is PERMUTED INTO STREAM ORDER once per run (lane i = i-th position: its slot, phase,
+        // row-pair mask, table offset, 8 seeds), so the loop body fetches it with v_readlane at a scalar index and spends
+        // ~25 scalar instructions per position.  (The scalar unit is shared by the CU's 16 waves: an earlier version that
+        // walked the bit masks in the loop -- ~150 scalar instructions per position -- was bound by it, the pair math did
+        // not matter.)  Candidate rows are requested kRing1 positions ahead, across phase boundaries: x is read-only, only
+        // the LDS update has to wait for its phase.
+        for (int ph0 = 0; ph0 < NW;) {
+            const int c0 = (wave + ph0) & (NW - 1);
+            const int h = c0 / cph, l00 = c0 - h * cph;
+            const int len = min(NW - ph0, cph - l00), ph1 = ph0 + len;  // phases [ph0, ph1): chunk lane offsets l00, l00 + 1, ...
+            MKB_TRACE_ONLY(const unsigned long long ts0 = __builtin_readcyclecounter();)
+            float gv[TI];
+            int items = 0, off_lo = 0, off_hi = 0, total = 0;
+            if (have) {  // this lane's slot of the half is (h, lane)
                 const int p_own = pb + npb * (lane * halves + h);
                 const bool valid = p_own < A.P;
-                unsigned nz = 0;
+                unsigned nz = 0, pm = 0;
 #pragma unroll
                 for (int r = 0; r < TI; ++r) {
                     gv[r] = (valid && i0 + r < A.B) ? A.G[(int64_t)(i0 + r) * A.P + p_own] : 0.f;
-                    nz |= __float_as_uint(gv[r]) << 1;  // +-0 -> unused pair (the loss kernel writes 0 for them)
+                    const unsigned u = __float_as_uint(gv[r]) << 1;  // +-0 -> unused pair (the loss kernel writes 0 for them)
+                    nz |= u;
+                    pm |= u ? (0x10000u << (r >> 1)) : 0u;
                 }
-                idv = valid ? (int)A.pool[p_own] : 0;
-                mask_h = __ballot(nz != 0);
-                if (lane == 0 && mask_h) atomicOr(&s_used[h], mask_h);
+                const int64_t off = (valid ? A.pool[p_own] : 0) * A.De;
+                const int rp = (lane % cph) - l00;  // phase of this lane's chunk, relative to the run
+                const bool part = nz != 0 && rp >= 0 && rp < len;
+                const unsigned long long used_h = __ballot(nz != 0), pmask = __ballot(part);
+                if (lane == 0 && used_h) atomicOr(&s_used[h], used_h);
+                // stream rank of this lane's position: positions of earlier phases + earlier lanes of the same chunk
+                int rank = 0, pre = 0;
+                for (int q = 0; q < len; ++q) {
+                    const unsigned long long mq = pmask & (cm << (l00 + q));
+                    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mq, 0u));
+                    rank = (rp == q) ? pre + below : rank;
+                    pre += __popcll(mq);
+                }
+                total = pre;
+                const unsigned long long rest = ~pmask;  // the other lanes take the ranks behind the stream: a full permutation
+                const int spare = __builtin_amdgcn_mbcnt_hi((unsigned)(rest >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rest, 0u));
+                const int dst = (part ? rank : total + spare) << 2;
+                items = __builtin_amdgcn_ds_permute(dst, (int)(pm | ((unsigned)rp << 8) | (unsigned)lane));
+                off_lo = __builtin_amdgcn_ds_permute(dst, (int)(unsigned)off);
+                off_hi = __builtin_amdgcn_ds_permute(dst, (int)(off >> 32));
+#pragma unroll
+                for (int r = 0; r < TI; ++r)
+                    gv[r] = __uint_as_float((unsigned)__builtin_amdgcn_ds_permute(dst, (int)__float_as_uint(gv[r])));
+            } else {
+#pragma unroll
+                for (int r = 0; r < TI; ++r) gv[r] = 0.f;
             }
-            // lanes of this chunk: l0, l0 + cph, ...
-            unsigned long long cm = 0x1ull;  // bit pattern with every cph-th bit set
-            cm = cph == 1 ? ~0ull : cph == 2 ? 0x5555555555555555ull : cph == 4 ? 0x1111111111111111ull
-                 : cph == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
-            unsigned long long rem = have ? (mask_h & (cm << l0)) : 0ull;
-            const int n = __popcll(rem);
-            if (n > 0) {
-                auto next_j = [&]() {  // next used slot of the chunk (scalar); past the end: repeats a harmless lane
-                    const int j = rem ? (int)__builtin_ctzll(rem) : 0;
-                    rem &= rem - 1ull;
-                    return j;
-                };
-                auto load_x = [&](int j, float (&d0)[KPT], float (&d1)[KPT]) {
-                    const float *x = A.ent + (int64_t)__builtin_amdgcn_readlane(idv, j) * A.De;
-                    load_units<CP, KPT>(x, A.d, NU, u0, d0, d1);
-                };
-                // One position ahead: the next candidate row's loads are issued before this position's 8 pair bodies
-                // (~500 cycles of VALU: more than an L2 hit).  A single loop body without unrolling keeps dq in place
-                // (an unrolled ring + branch-free variant, as in the two-pass kernels, spilled 30 VGPRs here).
-                float xn0[KPT], xn1[KPT];
-                int jn = next_j();
-                load_x(jn, xn0, xn1);
-                for (int it = 0; it < n; ++it) {
-                    const int j = jn;
+            auto load_item = [&](int idx, float (&d0)[KPT], float (&d1)[KPT]) {
+                const int64_t off = ((int64_t)__builtin_amdgcn_readlane(off_hi, idx) << 32) |
+                                    (int64_t)(unsigned)__builtin_amdgcn_readlane(off_lo, idx);
+                load_units<CP, KPT>(A.ent + off, A.d, NU, u0, d0, d1);
+            };
+            float xr0[kRing1][KPT], xr1[kRing1][KPT];
+            const int last = total - 1;
+            if (total > 0) {
+#pragma unroll
+                for (int k = 0; k < kRing1; ++k) load_item(min(k, last), xr0[k], xr1[k]);
+            }
+            MKB_TRACE_ONLY(tr_setup += __builtin_readcyclecounter() - ts0; tr_items += total;)
+            int cur = ph0;  // barriers passed = phase this wave is in
+            for (int it = 0; it < total; it += kRing1) {
+#pragma unroll
+                for (int k = 0; k < kRing1; ++k) {
+                    const int idx = it + k;
                     float x0[KPT], x1[KPT];
 #pragma unroll
-                    for (int v = 0; v < KPT; ++v) { x0[v] = xn0[v]; x1[v] = xn1[v]; }
-                    jn = next_j();
-                    load_x(jn, xn0, xn1);
+                    for (int v = 0; v < KPT; ++v) { x0[v] = xr0[k][v]; x1[v] = xr1[k][v]; }
+                    load_item(min(idx + kRing1, last), xr0[k], xr1[k]);
+                    if (idx >= total) continue;
+                    const unsigned word = (unsigned)__builtin_amdgcn_readlane(items, idx);  // slot | phase << 8 | pair mask << 16
+                    const int j = (int)(word & 63u), jph = ph0 + (int)((word >> 8) & 15u);
+                    // hand the chunks on: LDS writes done, then the barrier (global loads stay in flight)
+                    for (; cur < jph; ++cur) hand_on(g0 + cur + 1);
                     acc_t *slot = s_dx + (size_t)(h * 64 + j) * 64 + lane;
                     float dx0[KPT], dx1[KPT];
 #pragma unroll
                     for (int v = 0; v < KPT; ++v) { dx0[v] = 0.f; dx1[v] = 0.f; }
+                    float g[TI];
 #pragma unroll
-                    for (int r = 0; r < TI; ++r) {
-                        const float g = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r]), j));
-                        if ((__float_as_uint(g) << 1) != 0u) {  // wave-uniform: row r uses this position
-                            if constexpr (CP && KPT % 2 == 0) {
+                    for (int r = 0; r < TI; ++r)
+                        g[r] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r]), idx));
+                    auto one_row = [&](int r) {
+                        if constexpr (CP && KPT % 2 == 0) {
 #pragma unroll
-                                for (int v = 0; v < KPT; v += 2) {
-                                    f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
-                                    f2 br = f2{dx0[v], dx0[v + 1]}, bi = f2{dx1[v], dx1[v + 1]};
-                                    pair_bwd_cmod2_both(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
-                                                        f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]}, g, ar, ai, br, bi);
-                                    dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
-                                    dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
-                                    dx0[v] = br.x; dx0[v + 1] = br.y;
-                                    dx1[v] = bi.x; dx1[v + 1] = bi.y;
-                                }
-                            } else
+                            for (int v = 0; v < KPT; v += 2) {
+                                f2 ar = f2{dq0[r][v], dq0[r][v + 1]}, ai = f2{dq1[r][v], dq1[r][v + 1]};
+                                f2 br = f2{dx0[v], dx0[v + 1]}, bi = f2{dx1[v], dx1[v + 1]};
+                                pair_bwd_cmod2_both(f2{q0[r][v], q0[r][v + 1]}, f2{q1[r][v], q1[r][v + 1]},
+                                                    f2{x0[v], x0[v + 1]}, f2{x1[v], x1[v + 1]}, g[r], ar, ai, br, bi);
+                                dq0[r][v] = ar.x; dq0[r][v + 1] = ar.y;
+                                dq1[r][v] = ai.x; dq1[r][v + 1] = ai.y;
+                                dx0[v] = br.x; dx0[v + 1] = br.y;
+                                dx1[v] = bi.x; dx1[v + 1] = bi.y;
+                            }
+                        } else
 #pragma unroll
-                            for (int v = 0; v < KPT; ++v) {
-                                if constexpr (CP) {
-                                    Cplx dq, dx;
-                                    pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g, dq, dx);
-                                    dq0[r][v] += dq.re; dq1[r][v] += dq.im;
-                                    dx0[v] += dx.re; dx1[v] += dx.im;
-                                } else {
-                                    float dq, dx, e0 = 0.f;
-                                    pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g, A.kd, modulus, dq, dx, e0);
-                                    dq0[r][v] += dq;
-                                    dx0[v] += dx;
-                                    extra += g * e0;
-                                }
+                        for (int v = 0; v < KPT; ++v) {
+                            if constexpr (CP) {
+                                Cplx dq, dx;
+                                pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
+                                dq0[r][v] += dq.re; dq1[r][v] += dq.im;
+                                dx0[v] += dx.re; dx1[v] += dx.im;
+                            } else {
+                                float dq, dx, e0 = 0.f;
+                                pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
+                                dq0[r][v] += dq;
+                                dx0[v] += dx;
+                                extra += g[r] * e0;
                             }
                         }
+                    };
+#pragma unroll
+                    for (int r = 0; r < TI; r += 2) {
+#ifndef MKB_BWD1_NO_PAIR
+                        if constexpr (CP && KPT == 2) {
+                            // Rows go two at a time: two interleaved dependent chains fill each other's idle issue slots.  A row
+                            // of the pair that does not use the position carries g = 0 and adds exactly 0 (one body per pair
+                            // keeps the accumulators in place; alternative bodies cost register moves at their join).
+                            if (word & (0x10000u << (r >> 1))) {  // (scalar bit test: some row of the pair uses the position)
+                                f2 arA = f2{dq0[r][0], dq0[r][1]}, aiA = f2{dq1[r][0], dq1[r][1]};
+                                f2 arB = f2{dq0[r + 1][0], dq0[r + 1][1]}, aiB = f2{dq1[r + 1][0], dq1[r + 1][1]};
+                                f2 br = f2{dx0[0], dx0[1]}, bi = f2{dx1[0], dx1[1]};
+                                pair_bwd_cmod2_both_x2(f2{q0[r][0], q0[r][1]}, f2{q1[r][0], q1[r][1]}, f2{q0[r + 1][0], q0[r + 1][1]},
+                                                       f2{q1[r + 1][0], q1[r + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]}, g[r], g[r + 1],
+                                                       arA, aiA, arB, aiB, br, bi);
+                                dq0[r][0] = arA.x; dq0[r][1] = arA.y; dq1[r][0] = aiA.x; dq1[r][1] = aiA.y;
+                                dq0[r + 1][0] = arB.x; dq0[r + 1][1] = arB.y; dq1[r + 1][0] = aiB.x; dq1[r + 1][1] = aiB.y;
+                                dx0[0] = br.x; dx0[1] = br.y; dx1[0] = bi.x; dx1[1] = bi.y;
+                            }
+                            continue;
+                        }
+#endif
+                        if ((__float_as_uint(g[r]) << 1) != 0u) one_row(r);
+                        if ((__float_as_uint(g[r + 1]) << 1) != 0u) one_row(r + 1);
                     }
                     // this wave owns the chunk during the phase: plain read-modify-write (read late: 4 VGPRs less across the
                     // rows).  Component order: [re/real KPT][im KPT]
+#ifdef MKB_BWD1_NO_LDS
+                    acc_t upd = acc_t{};
+#else
                     acc_t upd = *slot;
+#endif
                     if constexpr (NC == 1) upd += dx0[0];
                     else if constexpr (NC == 2 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; }
                     else if constexpr (NC == 2) { upd.x += dx0[0]; upd.y += dx1[0]; }
                     else { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx1[0]; upd.w += dx1[1]; }
+#ifdef MKB_BWD1_NO_LDS
+                    if (A.B < 0) *slot = upd;
+#else
                     *slot = upd;
+#endif
                 }
             }
-            __syncthreads();  // hand the chunks on
+            for (; cur < ph1; ++cur) hand_on(g0 + cur + 1);
+            ph0 = ph1;
         }
         if (have) {
             float *dQs = A.dQ + (int64_t)pb * A.B * A.De;
@@ -815,24 +904,70 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         }
     }
     MKB_TRACE_T(tr_t2);
-    // LDS accumulator -> table gradient rows (slots no row of the group used are skipped); the last phase ended with a barrier
-    for (int sidx = wave; sidx < cap; sidx += NW) {
-        const int h = sidx >> 6, l = sidx & 63;
-        if (!((s_used[h] >> l) & 1ull)) continue;
-        const int p = pb + npb * (l * halves + h);
-        if (u0 < NU) {
-            float *row = A.g_ent + A.pool[p] * A.De;
-            const acc_t a = s_dx[(size_t)sidx * 64 + lane];
-            if constexpr (NC == 1) atomicAdd(row + u0, a);
-            else if constexpr (NC == 2 && !CP) { atomicAdd(row + u0, a.x); atomicAdd(row + u0 + 1, a.y); }
-            else if constexpr (NC == 2) { atomicAdd(row + u0, a.x); atomicAdd(row + A.d + u0, a.y); }
-            else {
-                atomicAdd(row + u0, a.x); atomicAdd(row + u0 + 1, a.y);
-                atomicAdd(row + A.d + u0, a.z); atomicAdd(row + A.d + u0 + 1, a.w);
-            }
+#ifdef MKB_TRACE_WG
+    if (lane == 0 && A.trace && A.trace_kind == 4) {  // per-wave record (tools/wgtrace.py run bwd1): cycles
+        unsigned long long *tr = A.trace + 8ull * ((unsigned long long)blockIdx.x * NW + wave);
+        tr[0] = __builtin_readcyclecounter() - tr_c0; tr[1] = tr_hand; tr[2] = tr_setup; tr[3] = 1; tr[4] = tr_items; tr[5] = wave; tr[6] = 0; tr[7] = blockIdx.x;
+    }
+#endif
+    __syncthreads();  // every wave's last phase is done
+    // LDS accumulator -> this row group's partial buffer (16 B per lane, 1 KB per slot and store: plain coalesced stores).
+    // pool_dx_reduce_kernel sums the row groups and adds the result to the table gradient rows: one fp32 atomic per element
+    // instead of one per element AND row group (8.4 M atomics at the headline shape, all issued when the workgroups finish
+    // together: 26-37 us of the launch).
+#ifdef MKB_BWD1_NO_FLUSH  // timing experiment only (tools/kbench.py): results are wrong without the flush
+    if (A.B > 0) return;
+#endif
+    {
+        const size_t wg = (size_t)rg * npb + pb;
+        if (s == 0 && tid < 8) A.xused[wg * 8 + tid] = tid < halves ? s_used[tid] : 0ull;
+        acc_t *out = reinterpret_cast<acc_t *>(A.dXp) + ((wg * cap) * A.dim_slices + s) * 64 + lane;
+        for (int sidx = wave; sidx < cap; sidx += NW) {
+            if (!((s_used[sidx >> 6] >> (sidx & 63)) & 1ull)) continue;
+            out[(size_t)sidx * A.dim_slices * 64] = s_dx[(size_t)sidx * 64 + lane];
         }
     }
     MKB_TRACE_OUT(A, 1, tr_t0, tr_t1, tr_t2, 0);
+}
+
+// Sums the row groups' dx partials of one slot and adds them to the slot's table gradient row.  One workgroup per
+// (block, slot); fixed summation order (row group 0, 1, ...): the only atomics left are the final adds (pool duplicates
+// and the positive triples' rows share gradient rows).
+template <int MODEL, int KPT>
+__global__ __launch_bounds__(256) void pool_dx_reduce_kernel(PoolArgs A, int row_groups) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int NC = KPT * (CP ? 2 : 1);
+    typedef typename AccVec<NC>::type acc_t;
+    const int halves = A.pb_halves, cap = halves * 64, npb = A.q_slices;
+    const int pb = blockIdx.x / cap, sidx = blockIdx.x - pb * cap;
+    const int h = sidx >> 6, l = sidx & 63;
+    const int p = pb + npb * (l * halves + h);
+    if (p >= A.P) return;
+    bool any = false;  // did any row group use the slot?
+    for (int rg = 0; rg < row_groups; ++rg) any |= ((A.xused[((size_t)rg * npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
+    if (!any) return;
+    const int NU = CP ? A.d : (int)A.De;
+    float *row = A.g_ent + A.pool[p] * A.De;
+    const acc_t *in = reinterpret_cast<const acc_t *>(A.dXp);
+    for (int e = threadIdx.x; e < A.dim_slices * 64; e += 256) {  // e = dim slice * 64 + lane
+        const int u0 = e * KPT;
+        if (u0 >= NU) continue;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int rg = 0; rg < row_groups; ++rg) {
+            if (!((A.xused[((size_t)rg * npb + pb) * 8 + h] >> l) & 1ull)) continue;
+            const acc_t v = in[(((size_t)rg * npb + pb) * cap + sidx) * A.dim_slices * 64 + e];
+            if constexpr (NC == 1) a[0] += v;
+            else if constexpr (NC == 2) { a[0] += v.x; a[1] += v.y; }
+            else { a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; }
+        }
+        if constexpr (NC == 1) atomicAdd(row + u0, a[0]);
+        else if constexpr (NC == 2 && !CP) { atomicAdd(row + u0, a[0]); atomicAdd(row + u0 + 1, a[1]); }
+        else if constexpr (NC == 2) { atomicAdd(row + u0, a[0]); atomicAdd(row + A.d + u0, a[1]); }
+        else {
+            atomicAdd(row + u0, a[0]); atomicAdd(row + u0 + 1, a[1]);
+            atomicAdd(row + A.d + u0, a[2]); atomicAdd(row + A.d + u0 + 1, a[3]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
@@ -841,8 +976,8 @@ struct PoolLaunch {
     int fkpt, fnw;        // the same for the forward kernel (it amortises its wave reduction over more units per lane)
     int fwd_slices, q_slices, x_slices;
     int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
-    int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the three below
-    int dim_slices, pb_halves, tiles_per_wave;
+    int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the four below
+    int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
@@ -882,7 +1017,7 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
 template <int MODEL, bool HEAD, int KPT>
 static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     constexpr int NC = KPT * (ModelTraits<MODEL>::cplx_pair ? 2 : 1);
-    const size_t lds = (size_t)L.pb_halves * 64 * NC * 64 * 4 + 64;
+    const size_t lds = (size_t)L.pb_halves * 64 * NC * 64 * 4 + 128;
     static size_t lds_ok = 0;  // per instantiation: opt in to more than 64 KB of dynamic LDS once
     if (lds > 64 * 1024 && lds > lds_ok) {
         MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT>),
@@ -895,6 +1030,8 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);
     hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT>), dim3(groups * L.q_slices * L.dim_slices),
                        dim3(kBwd1Waves * 64), lds, st, A2);
+    hipLaunchKernelGGL((pool_dx_reduce_kernel<MODEL, KPT>), dim3((unsigned)(L.q_slices * L.pb_halves * 64)), dim3(256), 0, st, A2,
+                       (int)groups);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

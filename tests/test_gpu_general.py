@@ -287,3 +287,141 @@ def test_top_k_reference_doctest_known_answers():
     assert top_k.top_relations(k=4, model=model, head="azerbaijan", tail="western_africa") == ["locatedin", "neighbor"]
     assert top_k.top_tails(k=4, model=model, head="western_africa", relation="neighbor") == [
         "afghanistan", "barbados", "taiwan", "new_caledonia"]
+
+
+def test_model_save_after_row_lazy_training_holds_only_the_model(tmp_path):
+    """models/base.py:41-46 (``save`` pickles the model on the CPU).  The row-lazy optimizer used to hang off the entity
+    Parameter, so the pickle swallowed its moments / replay constants and -- with a sampler drawn ahead -- died on the
+    ctypes handle.  The links now live in mkb_amd/_links.py: the file holds the model alone and loads without a GPU."""
+    import pickle
+
+    from mkb_amd import compose, datasets, evaluation, losses, models, optim, sampling
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(0)
+    m = models.TransE(hidden_dim=32, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+    big = torch.nn.Parameter(torch.zeros(5000, 32, device="cuda"))  # Umls' 135-row table stays dense: add a lazy one
+    opt = optim.Adam([p for p in m.parameters() if p.requires_grad] + [big], lr=1e-3, lazy_rows=True)
+    assert _links.owner(big) is opt and not hasattr(big, "_mkb_lazy")
+    ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    compose.Pipeline(epochs=1, eval_every=10).learn(model=m, dataset=ds, sampling=ns, optimizer=opt, loss=losses.Adversarial(alpha=0.5),
+                                                    evaluation=evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities,
+                                                                                     relations=ds.relations, batch_size=64, device="cuda"))
+    assert opt.draw_ahead is None or opt.draw_ahead is ns
+    path = tmp_path / "model.pkl"
+    want = m.entity_embedding.detach().cpu().clone()
+    m.save(path)
+    assert path.stat().st_size < 4 * (135 * 32 + 46 * 32) * 4 + 200_000  # the two tables and the label dicts, not an optimizer
+    loaded = pickle.loads(path.read_bytes())
+    assert type(loaded).__name__ == "TransE" and not loaded.entity_embedding.is_cuda
+    assert torch.equal(loaded.entity_embedding.detach(), want)
+    assert not any(k.startswith("_mkb") for k in vars(loaded.entity_embedding))
+
+
+def test_row_lazy_model_save_with_a_sampler_drawn_ahead(tmp_path):
+    """The documented fast path: lazy_rows Adam + draw_ahead sampler on a big table, then save()."""
+    import pickle
+
+    from mkb_amd import models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    N, R = 6000, 5
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(0)
+    train = np.stack([rs.randint(N, size=4000), rs.randint(R, size=4000), rs.randint(N, size=4000)], 1)
+    torch.manual_seed(0)
+    m = models.RotatE(hidden_dim=16, entities=ents, relations=rels, gamma=6.0).cuda()
+    ns = sampling.NegativeSampling(size=16, train_triples=train, entities=ents, relations=rels, seed=1)
+    opt = optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-3, lazy_rows=True, draw_ahead=ns)
+    step = FusedTrainStep(m, 1.0)
+    t = torch.as_tensor(train).cuda()
+    for i in range(3):
+        step.sampled(t[i * 64: (i + 1) * 64].contiguous(), torch.ones(64, device="cuda"), ns, "head-batch" if i % 2 else "tail-batch")
+        opt.step()
+        opt.zero_grad()
+    dense = m.entity_embedding.detach().clone()
+    opt.flush()
+    path = tmp_path / "m.pkl"
+    m.save(path)  # used to raise: ctypes objects containing pointers cannot be pickled
+    loaded = pickle.loads(path.read_bytes())
+    assert path.stat().st_size < 2 * N * 32 * 4
+    np.testing.assert_array_equal(loaded.entity_embedding.detach().numpy(), m.entity_embedding.detach().cpu().numpy())
+    assert dense.shape == loaded.entity_embedding.shape
+
+
+def test_two_fused_steps_before_one_optimizer_step_accumulate_their_touched_rows():
+    """Gradient accumulation with the row-lazy optimizer: the rows of BOTH batches take the step and are cleared
+    (the touched list of the first batch used to be overwritten by the second)."""
+    from mkb_amd import models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    N, R = 5000, 4
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(1)
+    train = np.stack([rs.randint(N, size=3000), rs.randint(R, size=3000), rs.randint(N, size=3000)], 1)
+    t = torch.as_tensor(train).cuda()
+    w = torch.ones(32, device="cuda")
+
+    def run(lazy):
+        torch.manual_seed(3)
+        m = models.TransE(hidden_dim=16, entities=ents, relations=rels, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=16, train_triples=train, entities=ents, relations=rels, seed=1)
+        opt = optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-2, lazy_rows=lazy)
+        step = FusedTrainStep(m, 1.0)
+        for it in range(3):
+            for half in range(2):  # two backward passes per optimizer step
+                s = t[(2 * it + half) * 32: (2 * it + half + 1) * 32].contiguous()
+                step(s, w, ns.generate(s, "tail-batch"), "tail-batch")
+            opt.step()
+            opt.zero_grad()
+            assert not m.entity_embedding.grad.any(), "stale gradient rows survived the step"
+        if lazy:
+            opt.flush()
+        return m.entity_embedding.detach().clone()
+
+    assert torch.equal(run(True), run(False))
+
+
+def test_collapsed_or_diverged_model_does_not_rank_first():
+    """evaluation.py:245-262 sorts the scores; a target tied with everything (collapsed model) or NaN (diverged model) sits
+    somewhere in the pack there.  The device ranking must not report rank 1 for it (it used to: nothing compares greater)."""
+    from mkb_amd import datasets, evaluation, models
+
+    ds = datasets.CountriesS1(batch_size=8, seed=42, num_workers=0)
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=8,
+                               device="cuda", num_workers=0)
+    m = models.TransE(hidden_dim=8, entities=ds.entities, relations=ds.relations, gamma=3.0).cuda()
+    with torch.no_grad():
+        m.entity_embedding.zero_()  # every candidate scores the same
+        m.relation_embedding.zero_()
+    res = ev.eval(model=m, dataset=ds.test)
+    assert res["HITS@1"] < 0.2 and res["MRR"] < 0.5 and res["MR"] > 10, res
+    rel = ev.eval_relations(model=m, dataset=ds.test)
+    assert rel["MR_relations"] > 1.0, rel
+    with torch.no_grad():
+        m.entity_embedding.fill_(float("nan"))
+    res = ev.eval(model=m, dataset=ds.test)
+    assert res["HITS@1"] < 0.2 and res["MR"] > 10, res
+
+
+def test_pipeline_on_device_batches_trains_and_matches_dataset_order_without_shuffle(capsys):
+    """Pipeline.device_batches (opt-in): with shuffle=False the device producer yields the dataset's own
+    batches, so the run must end with the very same tables as the default host producer."""
+    from mkb_amd import compose, datasets, losses, models, optim, sampling
+
+    def run(device_batches):
+        ds = datasets.Umls(batch_size=128, shuffle=False, seed=42, num_workers=0)
+        torch.manual_seed(5)
+        m = models.RotatE(hidden_dim=20, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=16, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+        opt = optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-3)
+        pipe = compose.Pipeline(epochs=2, eval_every=100, device="cuda")
+        pipe.device_batches = device_batches
+        pipe.learn(model=m, dataset=ds, sampling=ns, optimizer=opt, loss=losses.Adversarial(alpha=0.5),
+                   evaluation=__import__("mkb_amd").evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities,
+                                                                         relations=ds.relations, batch_size=64, device="cuda"))
+        return m.entity_embedding.detach().clone(), pipe.test_scores
+
+    a, sa = run(False)
+    b, sb = run(True)
+    assert torch.equal(a, b) and sa == sb

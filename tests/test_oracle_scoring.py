@@ -104,19 +104,32 @@ def test_init_doctest_known_answers(golden, name):
         np.testing.assert_allclose(g[f"{name}/locatedin"], doc[name][1], atol=5e-5)
 
 
-def test_headline_slice(golden):
-    """Real shape: FB15k-237 RotatE hidden=1000, K=256 (16-row slice of a batch)."""
-    g = golden("headline_slice.npz")
-    from mkb_amd import datasets
+def test_headline_shape_slice_matches_reference(golden):
+    """FB15k-237 RotatE hidden=1000 K=256, 16 rows: the oracle's scores, loss and dense gradients against the live
+    reference's (tests/golden/headline_slice.npz) -- the shape the full-size GPU tests check the kernels at."""
+    import pathlib
 
-    ds = datasets.Fb15k237(batch_size=16, shuffle=False, seed=42, num_workers=0)
-    torch.manual_seed(42)
-    tb = scoring.init_tables("RotatE", ds.n_entity, ds.n_relation, 1000, 9.0)
-    if not np.array_equal(tb.ent[[0, 7270, 14540]].numpy(), g["ent_rows_pin"]):
-        pytest.skip("torch CPU RNG stream differs from the build container's")
-    s = torch.LongTensor(np.asarray(ds.train)[g["idx"]])
-    np.testing.assert_allclose(scoring.score(tb, s).numpy(), g["pos"], rtol=0, atol=1e-5)
-    for mode in ["head-batch", "tail-batch"]:
-        neg = torch.LongTensor(g[f"{mode}/neg"].astype(np.int64))
-        got = scoring.score(tb, s, neg, mode, fast_norm=True)
-        np.testing.assert_allclose(got.numpy(), g[f"{mode}/score"], rtol=0, atol=1e-5)
+    from util_gpu_tables import headline_tables
+
+    g = golden("headline_slice.npz")
+    ent, rel = headline_tables(seed=int(g["table_seed"]))
+    tb = scoring.Tables("RotatE", 1000, 9.0, torch.from_numpy(ent), torch.from_numpy(rel), torch.tensor([[0.5 * 11.0 / 1000]]))
+    data = pathlib.Path(scoring.__file__).resolve().parent.parent / "mkb_amd" / "datasets" / "data" / "fb15k237.npz"
+    train = np.load(data)["train"].astype(np.int64)
+    s, w = torch.as_tensor(train[g["idx"]]), torch.as_tensor(g["weight"])
+    for mode in ("head-batch", "tail-batch"):
+        neg = torch.as_tensor(g[f"{mode}/neg"].astype(np.int64))
+        r = scoring.train_step_grads(tb, s, neg, w, mode, float(g["alpha"]))
+        np.testing.assert_array_equal(r["pos"].numpy(), g[f"{mode}/pos"])
+        np.testing.assert_array_equal(r["neg"].numpy(), g[f"{mode}/score"])
+        np.testing.assert_allclose(r["loss"].item(), float(g[f"{mode}/loss"]), rtol=0, atol=1e-7)
+        ge = r["g_ent"].numpy()
+        rows = g[f"{mode}/g_ent_rows"].astype(np.int64)
+        assert np.array_equal(np.flatnonzero(np.abs(ge).sum(1) > 0), rows)
+        np.testing.assert_allclose(ge[rows][:, ::8], g[f"{mode}/g_ent_cols8"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(ge[rows].astype(np.float64).sum(1), g[f"{mode}/g_ent_rowsum"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(r["g_rel"].numpy()[g[f"{mode}/g_rel_rows"].astype(np.int64)], g[f"{mode}/g_rel"], rtol=0, atol=1e-7)
+        # the sqrt(re^2 + im^2) form the GPU tests use as their fast oracle agrees with the reference-faithful one
+        f = scoring.train_step_grads(tb, s, neg, w, mode, float(g["alpha"]), fast_norm=True)
+        np.testing.assert_allclose(f["neg"].numpy(), r["neg"].numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(f["g_ent"].numpy(), ge, rtol=0, atol=1e-6)

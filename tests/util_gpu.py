@@ -40,3 +40,6 @@ def random_problem(name, N, R, hidden, B, K, seed, gamma=6.0):
     w = torch.rand(B, generator=g) + 0.1
     modulus = torch.tensor([[0.5 * rng]]) if name in ("RotatE", "pRotatE") else None
     return ent, rel, sample, neg, w, modulus
+
+
+from util_gpu_tables import headline_tables  # noqa: E402,F401  (re-exported for the GPU tests)

@@ -24,7 +24,7 @@ def build():
 
 def run(kind="bwd_x", step=10):
     step = int(step)
-    kind_id = {"fwd": 0, "bwd_q": 1, "bwd_x": 2, "all": 3}[kind]
+    kind_id = {"fwd": 0, "bwd_q": 1, "bwd_x": 2, "all": 3, "bwd1": 4}[kind]
     os.environ["MKB_HIP_LIB"] = str(VDIR / "lib_trace.so")
     import numpy as np
     import torch
@@ -45,6 +45,16 @@ def run(kind="bwd_x", step=10):
         bench.run_step(ctx, step + 2 * i)
     torch.cuda.synchronize()
     lib.mkb_debug_set_trace(None, kind_id)
+    if kind == "bwd1":  # per-wave cycle accounts of the single-pass backward (wave loop, hand-off waits, run setup)
+        t = buf.cpu().numpy().reshape(-1, 8)
+        t = t[t[:, 3] != 0].astype(np.float64)
+        print(f"waves {len(t)}  loop cycles mean {t[:, 0].mean():.0f} (min {t[:, 0].min():.0f} max {t[:, 0].max():.0f})  "
+              f"hand-off wait mean {t[:, 1].mean():.0f} max {t[:, 1].max():.0f}  run setup mean {t[:, 2].mean():.0f}  "
+              f"positions per wave mean {t[:, 4].mean():.1f} max {t[:, 4].max():.0f}")
+        for w in range(16):
+            m = t[:, 5] == w
+            print(f"  wave {w:2d}: loop {t[m, 0].mean():8.0f}  hand-off {t[m, 1].mean():8.0f}  setup {t[m, 2].mean():7.0f}  items {t[m, 4].mean():5.1f}")
+        return
     if kind == "all":  # the three kernels of one step on one clock: where does the time between them go?
         raw = buf.cpu().numpy().reshape(3, 4096, 8)
         base = None
