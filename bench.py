@@ -77,29 +77,48 @@ def build(device, rank, world, seed=42, parallelism="dims"):
     torch.manual_seed(seed)
     model = getattr(models, MODEL)(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA)
     dims = world > 1 and parallelism == "dims"
-    model = parallel.shard_dims(model, rank, world, device) if dims else model.to(device)
+    trows = world > 1 and parallelism == "table-rows"
+    table = rel_rep = None
+    if trows:  # entity table, its gradient and its Adam state sharded by ROW (owner = id % world); relation table replicated
+        from mkb_amd.table_rows import TableRowShardedStep, shard_table_rows
+
+        table, rel_rep = shard_table_rows(model, device=device)
+    else:
+        model = parallel.shard_dims(model, rank, world, device) if dims else model.to(device)
     sampler = sampling.NegativeSampling(size=K, train_triples=train_np, entities=ents, relations=rels, seed=seed)
     # dense-Adam semantics, evaluated row-lazily (bit-identical to the dense kernel, tests/test_gpu_general.py);
     # MKB_BENCH_DENSE_ADAM=1 selects the plain dense streaming kernel instead
     lazy = os.environ.get("MKB_BENCH_DENSE_ADAM", "0") != "1"
-    opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
-                     lr=LR, lazy_rows=lazy, draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None)
-    step = parallel.DimShardedStep(model, ALPHA) if dims else FusedTrainStep(model, ALPHA)
+    if trows:
+        opt = optim.Adam([table.data, rel_rep], lr=LR)  # dense Adam on this rank's shard: no optimizer communication
+        step = TableRowShardedStep(table, rel_rep, ALPHA, model_cls=getattr(models, MODEL), hidden_dim=HIDDEN, gamma=GAMMA)
+    else:
+        opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
+                         lr=LR, lazy_rows=lazy, draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None)
+        step = parallel.DimShardedStep(model, ALPHA) if dims else FusedTrainStep(model, ALPHA)
     train = torch.as_tensor(train_np, device=device)
     weights = subsampling_weights(train_np).to(device)
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(len(train_np), generator=g).to(device)
     train, weights = train[perm].contiguous(), weights[perm].contiguous()  # shuffled once (per epoch in a real loop):
     return dict(ride=os.environ.get("MKB_BENCH_NO_RIDE", "0") != "1", model=model, sampler=sampler, opt=opt, step=step, train=train, weights=weights, perm=perm, rank=rank,  # batches are views
-                world=world, n_train=len(train_np), exchange=None, dims=dims)
+                world=world, n_train=len(train_np), exchange=None, dims=dims, trows=trows, table=table)
 
 
 def run_step(ctx, i):
     """One training step for this rank's rows of global batch i."""
     n, world, rank = ctx["n_train"], ctx["world"], ctx["rank"]
     mode = "head-batch" if i % 2 == 0 else "tail-batch"
+    Bl = ctx.get("rows_per_rank", B)  # rows per rank (weak scaling: B; strong scaling: B / world)
+    if ctx.get("trows"):  # row-sharded entity table: this rank's rows of the global batch, ONE shared pool (replicated RNG)
+        lo = ((i * world + rank) * Bl) % (n - Bl)
+        sample, weight = ctx["train"][lo: lo + Bl], ctx["weights"][lo: lo + Bl]
+        loss = ctx["step"](sample, weight, ctx["sampler"].generate(sample, mode), mode)
+        ctx["opt"].step()
+        ctx["opt"].zero_grad()
+        return loss
     if ctx["dims"]:  # dimension sharding: every rank scores ALL world*B rows of the global batch on its 1/world of the dims
-        gb = world * B
+        gb = world * Bl
         lo = (i * gb) % (n - gb)
         sample, weight = ctx["train"][lo: lo + gb], ctx["weights"][lo: lo + gb]
         if ctx.get("ride", True):
@@ -109,9 +128,9 @@ def run_step(ctx, i):
         ctx["opt"].step()
         ctx["opt"].zero_grad()
         return loss
-    lo = ((i * world + rank) * B) % (n - B)
-    sample = ctx["train"][lo: lo + B]
-    weight = ctx["weights"][lo: lo + B]
+    lo = ((i * world + rank) * Bl) % (n - Bl)
+    sample = ctx["train"][lo: lo + Bl]
+    weight = ctx["weights"][lo: lo + Bl]
     ex = ctx["exchange"]
     wsum = ex.weight_sum(weight) if ex is not None else None   # global-batch normaliser (all-reduced scalar)
     if ctx.get("ride", True):  # sampler folded into the optimizer's catch-up launch (identical negatives)
@@ -292,9 +311,13 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the with/without optimizer & sampler step variants")
     ap.add_argument("--profile-kernel", default="auto", help="kernel class bracketed with HIP events (or 'none')")
     ap.add_argument("--breakdown", action="store_true", help="also print per-phase timings (stderr)")
-    ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "dims"), choices=["dims", "rows"],
+    ap.add_argument("--scaling", default=os.environ.get("MKB_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="N>1: weak = 1024 rows per GPU (global batch N*1024); strong = global batch fixed at 1024 rows")
+    ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "dims"), choices=["dims", "rows", "table-rows"],
                     help="N>1: 'dims' = shard the embedding dimension (one all-reduce of partial scores per step, no "
-                         "gradient exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce")
+                         "gradient exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce; 'table-rows' = "
+                         "entity table + gradient + Adam state sharded by row (BASELINE config 5's partitioning): pool rows by "
+                         "all-reduce, positive rows by all-to-all, gradients back the same way")
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (default: the headline; the others are for profiles/)")
     ap.add_argument("--mrr-epochs", type=int, default=10,
@@ -326,7 +349,8 @@ def main():
     from mkb_amd import _hip
 
     ctx = build(device, rank, world, parallelism=args.parallelism)
-    if world > 1 and not ctx["dims"]:
+    ctx["rows_per_rank"] = B if (args.scaling == "weak" or world == 1) else max(8, B // world)
+    if world > 1 and not ctx["dims"] and not ctx["trows"]:
         from mkb_amd import parallel
 
         ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], equal_batches=True)
@@ -368,7 +392,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = run_step(ctx, args.warmup + 8 + i)
-    ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work
+    ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
     t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
     barrier()
     dt = time.perf_counter() - t0
@@ -387,7 +411,7 @@ def main():
         sampler_note = f"sampler: {e}"
     assert torch.isfinite(loss).item() or sampler_note
     if world > 1:  # rows: replicas must hold identical tables; dims: every rank must have computed the same loss
-        probe = (loss.detach().double().reshape(1) if ctx["dims"]
+        probe = (loss.detach().double().reshape(1) if (ctx["dims"] or ctx["trows"])
                  else ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1))
         lo_, hi_ = probe.clone(), probe.clone()
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
@@ -407,11 +431,11 @@ def main():
         return
     if sampler_note:
         print(sampler_note, file=sys.stderr)
-    triples_per_step = world * B * (K + 1)
+    triples_per_step = world * ctx["rows_per_rank"] * (K + 1)
     value = triples_per_step * args.steps / dt
     m_ = ctx["model"]
     De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation  # per rank (dims: 1/world of the row)
-    Bk = world * B if ctx["dims"] else B                                        # rows each rank's kernels see
+    Bk = world * ctx["rows_per_rank"] if ctx["dims"] else ctx["rows_per_rank"]  # rows each rank's kernels see
     roof = None
     if launches:
         avg_s = kms / launches / 1e3
@@ -469,16 +493,17 @@ def main():
         "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
         else f"scored triples/sec (pos+K neg), {args.config}", "value": value, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
         "data": (f"{DATASET} train triples (packaged asset" + ("; SYNTHETIC triples: train.csv absent upstream" if DATASET == "yago310" else "")
                  + "), random-init tables (torch.manual_seed(42)), synthetic batch order"),
         "config": {"workload": ("BASELINE configs[2]: " if args.config == "headline" else f"{args.config}: ")
                                + f"datasets.{DATASET} + models.{MODEL} hidden_dim={HIDDEN}, K={K}, batch {B}/GPU, "
                                f"Adversarial alpha={ALPHA}, gamma={GAMMA}, dense Adam lr={LR} (row-lazy exact evaluation); "
                                "step = sampler + pos/neg forward + loss + backward + Adam",
-                   "global_batch": world * B, "negatives": K, "parallelism": (f"dims{world} (embedding dimension sharded, 1 score all-reduce/step)"
-                                                                if ctx["dims"] else f"dp{world} (rows, sparse grad all-reduce)")
-                   if world > 1 else "single"},
+                   "global_batch": world * ctx["rows_per_rank"], "negatives": K,
+                   "parallelism": ((f"dims{world} (embedding dimension sharded, 1 score all-reduce/step)" if ctx["dims"] else
+                                    f"table-rows{world} (entity table + Adam state sharded by row; pool rows all-reduce, positive rows all-to-all)"
+                                    if ctx["trows"] else f"dp{world} (rows, sparse grad all-reduce)") if world > 1 else "single")},
         "loss": float(loss.item()),
         "roofline": roof,
     }

@@ -147,6 +147,17 @@ int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int6
                        const uint16_t *cnt, int64_t B, int64_t K, int mode, const float *dpool_score, void *ws,
                        void *stream);
 
+/* ---- distillation loss --------------------------------------------------------------------------------
+ * == losses.KlDivergence()(student_score, teacher_score, T) (losses/kl_divergence.py:22-29), called by
+ * distillation.Distillation.distill (distillation/distillation.py:633-683) from KdmkbModel.forward
+ * (distillation/kdmkb_model.py:337-349): mean over all n*m entries of t (log t - log p), t = softmax(teacher / T, dim=1),
+ * p = softmax(student / T, dim=1).  student, teacher: [n, m] row-major.  loss: 1 float.  dstudent [n, m] = d loss / d
+ * student; dteacher [n, m] = d loss / d teacher, or null (the reference scores the teacher under no_grad).
+ * scratch: n floats.
+ */
+int mkb_kl_divergence(const float *student, const float *teacher, int64_t n, int64_t m, float T, float *loss,
+                      float *dstudent, float *dteacher, float *scratch, void *stream);
+
 /* ---- dense Adam --------------------------------------------------------------------------------------
  * == torch.optim.Adam(lr, betas, eps).step() + zero_grad() for one parameter tensor as the README loop
  * uses it (README.md:123-126, pipeline.py:238-240): every element moves every step.  step is 1-based.

@@ -10,6 +10,8 @@ Same public names as the reference for the path it replaces::
 * ``compose.Pipeline``                                 same training loop; fused step when it can
 * ``evaluation.Evaluation``                            filtered ranking on device
 * ``datasets``                                         host-side batch producer (same torch DataLoader order)
+* ``distillation.{Distillation,KdmkbModel}`` + ``losses.KlDivergence``   second consumer of the scoring kernels
+* ``table_rows`` / ``parallel``                        multi-GPU partitionings (row-sharded table, dims, batch rows)
 
 All arithmetic runs in ``libmkb_hip.so`` (C ABI declared in ``include/mkb_hip.h``), loaded with ctypes by
 ``mkb_amd._hip``.  There is NO CPU compute fallback: tensors must live on a ROCm device and a missing
@@ -17,6 +19,6 @@ library raises at first use.
 """
 __version__ = "0.1.0"
 
-from . import compose, datasets, evaluation, fused, losses, models, optim, sampling, utils  # noqa: F401
+from . import compose, datasets, distillation, evaluation, fused, losses, models, optim, sampling, table_rows, utils  # noqa: F401
 
-__all__ = ["compose", "datasets", "evaluation", "fused", "losses", "models", "optim", "sampling", "utils"]
+__all__ = ["compose", "datasets", "distillation", "evaluation", "fused", "losses", "models", "optim", "sampling", "table_rows", "utils"]

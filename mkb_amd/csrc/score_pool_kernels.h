@@ -657,6 +657,8 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_kernel(PoolArgs A) {
 //               group: 8 per element at the headline shape, as before); dq partial stored once per wave and block.
 // Nothing is recomputed: RotatE 9 packed ops + 2 v_rsq per two complex dims (the two-pass kernels: 14 + 4).
 constexpr int kBwd1Waves = 16;
+constexpr int kChunkStride = 1;                         // chunks (= phases) between a wave and the next wave of the chain
+constexpr int kChunks = kBwd1Waves * kChunkStride;      // chunks per block = phases per tile
 
 template <int NC> struct AccVec;
 template <> struct AccVec<1> { typedef float type; };
@@ -682,7 +684,8 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     const int npb = A.q_slices, pb = b % npb, rg = b / npb;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = (s * 64 + lane) * KPT;
-    const int cph = NW / halves;  // chunks per half; chunk c = lanes l == c % cph (mod cph) of half c / cph
+    // The block's slots are cut into kChunks = 4 x 16 chunks, 4 per wave: chunk c = lanes l == c % cph (mod cph) of half c / cph
+    const int cph = kChunks / halves;
     MKB_TRACE_T(tr_t0);
     MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
 
@@ -712,23 +715,40 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         }
         float extra = 0.f;
         // lanes of chunk c of a half: l0, l0 + cph, ... (bit pattern with every cph-th bit set, shifted by l0)
-        const unsigned long long cm = cph == 1 ? ~0ull : cph == 2 ? 0x5555555555555555ull : cph == 4 ? 0x1111111111111111ull
-                                      : cph == 8 ? 0x0101010101010101ull : 0x0001000100010001ull;
-        // Hand-off between phases.  Chunk (v + g) mod 16 of wave v in (global) phase g was wave v + 1's chunk in phase g - 1,
-        // wave v + 2's before that, ...: wave v may enter phase g as soon as wave v + 1 has finished phase g - 1 (which, by
-        // the same rule, implies every earlier owner has).  So instead of a workgroup barrier per phase -- 16 drains per
+        const unsigned long long cm = cph == 8 ? 0x0101010101010101ull : cph == 16 ? 0x0001000100010001ull
+                                      : cph == 32 ? 0x0000000100000001ull : 0x1ull;
+        // Hand-off between phases.  Wave v owns chunk (4 v + g) mod 64 in (global) phase g; that chunk was wave v + 1's in
+        // phase g - 4, wave v + 2's in phase g - 8, ...: wave v may enter phase g as soon as wave v + 1 has finished phase
+        // g - 4 (which, by the same rule, implies every earlier owner has).  Four chunks per wave instead of one give the chain
+        // 3 phases of slack per link (12-16 between the four waves that share a SIMD): in steady state nobody waits and the
+        // SIMD always has several runnable waves (with one chunk per wave, every wave spent half its loop time waiting for
+        // its predecessor -- per-wave cycle accounts of tools/wgtrace.py -- and the waves of a SIMD ran one at a time).  So instead of a workgroup barrier per phase -- 16 drains per
         // tile with the SIMDs running out of ready waves at each (PMC: waves parked 55 % of their lifetime, VALU busy 44 %)
         // -- each wave publishes its finished-phase count in LDS and waits for its ONE predecessor only; the waves fall
         // into a staggered pipeline.  LDS operations of a wave are performed in order, so the count lands after the data.
-        const int g0 = t * NW, pred = (wave + 1) & (NW - 1);
+        const int g0 = t * kChunks, pred = (wave + 1) & (NW - 1);
         auto hand_on = [&](int finished) {
             if (lane == 0) __hip_atomic_store(&s_done[wave], have ? finished : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (!have) return;
             MKB_TRACE_ONLY(const unsigned long long th0 = __builtin_readcyclecounter();)
-            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done[pred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < finished)
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done[pred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < finished - (kChunkStride - 1))
                 __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             MKB_TRACE_ONLY(tr_hand += __builtin_readcyclecounter() - th0;)
+#ifndef MKB_BWD1_NO_FAIR
+            // Fair share of the SIMD: the hardware issues oldest-first, which lets the oldest wave of each SIMD run a phase
+            // ahead, block on the chain, then the next oldest ... -- the four waves of a SIMD end up running one at a
+            // time (per-wave trace: half of every wave's loop time was hand-off wait) and a lone wave cannot fill the VALU.
+            // A wave that is ahead of a SIMD mate (waves w, w+4, w+8, w+12 share a SIMD) drops to priority 0, the others
+            // run at 3: the four stay within a phase of each other and interleave instruction by instruction.
+            int behind = 0x3fffffff;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                behind = min(behind, __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done[(wave + 4 * k) & (NW - 1)], __ATOMIC_RELAXED,
+                                                                                       __HIP_MEMORY_SCOPE_WORKGROUP)));
+            if (finished > behind) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(3);
+#endif
         };
         // The 16 phases of a tile split into RUNS of consecutive phases whose chunks lie in the same half (the seeds and ids
         // of one half fit the lanes).  Inside a run the wave's used positions form one stream, ordered by phase: everything
@@ -738,10 +758,10 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         // walked the bit masks in the loop -- ~150 scalar instructions per position -- was bound by it, the pair math did
         // not matter.)  Candidate rows are requested kRing1 positions ahead, across phase boundaries: x is read-only, only
         // the LDS update has to wait for its phase.
-        for (int ph0 = 0; ph0 < NW;) {
-            const int c0 = (wave + ph0) & (NW - 1);
+        for (int ph0 = 0; ph0 < kChunks;) {
+            const int c0 = (kChunkStride * wave + ph0) & (kChunks - 1);
             const int h = c0 / cph, l00 = c0 - h * cph;
-            const int len = min(NW - ph0, cph - l00), ph1 = ph0 + len;  // phases [ph0, ph1): chunk lane offsets l00, l00 + 1, ...
+            const int len = min(kChunks - ph0, cph - l00), ph1 = ph0 + len;  // phases [ph0, ph1): chunk lane offsets l00, l00 + 1, ...
             MKB_TRACE_ONLY(const unsigned long long ts0 = __builtin_readcyclecounter();)
             float gv[TI];
             int items = 0, off_lo = 0, off_hi = 0, total = 0;
@@ -806,7 +826,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                     load_item(min(idx + kRing1, last), xr0[k], xr1[k]);
                     if (idx >= total) continue;
                     const unsigned word = (unsigned)__builtin_amdgcn_readlane(items, idx);  // slot | phase << 8 | pair mask << 16
-                    const int j = (int)(word & 63u), jph = ph0 + (int)((word >> 8) & 15u);
+                    const int j = (int)(word & 63u), jph = ph0 + (int)((word >> 8) & 63u);
                     // hand the chunks on: LDS writes done, then the barrier (global loads stay in flight)
                     for (; cur < jph; ++cur) hand_on(g0 + cur + 1);
                     acc_t *slot = s_dx + (size_t)(h * 64 + j) * 64 + lane;

@@ -1,0 +1,135 @@
+"""``KdmkbModel`` -- joint training of several KGE models that teach each other (reference
+mkb/distillation/kdmkb_model.py:19-577; the hot part is ``forward``, :286-360).
+
+Per step and dataset: one batch, positive forward, filtered negatives, negative forward, ``Adversarial`` scaled by
+``1 - weight_kl``; then every (teacher, student) pair adds ``Distillation.distill`` on the teacher's batch scaled by
+``weight_kl``; backward, ``optimizer.step()``, ``zero_grad()``, rolling mean of the loss.  All scoring runs on the HIP
+kernels (2-D samples: pooled path for the negatives; 3-D distillation samples: general forward).
+
+Two deliberate differences from the reference, both at its edges: the candidate sampler defaults to ``UniformSampling``
+(the reference hard-wires ``FastTopKSampling``, which needs the third-party ``faiss`` index -- pass another
+``sampling_method`` to use one), and classification datasets (ConvE / BCE) are outside the mkb_amd hot path.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from ..evaluation import Evaluation
+from ..losses import Adversarial
+from ..sampling import NegativeSampling
+from ..utils import BarRange, RollingMean
+from .distillation import Distillation
+from .uniform_sampling import UniformSampling
+
+__all__ = ["KdmkbModel"]
+
+
+class KdmkbModel:
+    def __init__(self, models, datasets, lr, alpha_kl, alpha_adv, negative_sampling_size, batch_size_entity,
+                 batch_size_relation, n_random_entities, n_random_relations, update_distillation_every=500, device="cuda",
+                 seed=None, warm_step=500, sampling_method=UniformSampling):
+        self.alpha_kl = alpha_kl
+        self.batch_size_entity, self.batch_size_relation = batch_size_entity, batch_size_relation
+        self.n_random_entities, self.n_random_relations = n_random_entities, n_random_relations
+        self.update_distillation_every, self.device, self.seed, self.warm_step = update_distillation_every, device, seed, warm_step
+        self.sampling_method = sampling_method
+        self._rng = np.random.RandomState(seed)
+        ids = list(datasets)
+        for key, dataset in datasets.items():
+            if dataset.classification:
+                raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
+        self.loss_function = collections.OrderedDict((k, Adversarial(alpha=alpha_adv[k])) for k in ids)
+        self.optimizers = collections.OrderedDict(
+            (k, torch.optim.Adam(filter(lambda p: p.requires_grad, models[k].parameters()), lr=rate)) for k, rate in lr.items())
+        self.distillation = collections.OrderedDict()
+        for teacher in ids:
+            for student in ids:
+                if teacher != student:
+                    self.distillation[f"{teacher}_{student}"] = self._make_distillation(models, datasets, teacher, student)
+        self.negative_sampling = collections.OrderedDict(
+            (k, NegativeSampling(size=negative_sampling_size[k], entities=d.entities, relations=d.relations,
+                                 train_triples=d.train_triples, seed=seed)) for k, d in datasets.items())
+        self.validation = collections.OrderedDict(
+            (k, Evaluation(entities=d.entities, relations=d.relations, batch_size=2, true_triples=d.true_triples, device=device))
+            for k, d in datasets.items())
+        self.metrics = {k: RollingMean(1000) for k in ids}
+
+    def _make_distillation(self, models, datasets, teacher, student):
+        dt, ds = datasets[teacher], datasets[student]
+        sampling = self.sampling_method(teacher=models[teacher], dataset_teacher=dt, teacher_relations=dt.relations,
+                                        teacher_entities=dt.entities, student_entities=ds.entities,
+                                        student_relations=ds.relations, batch_size_entity=self.batch_size_entity[teacher],
+                                        batch_size_relation=self.batch_size_relation[teacher],
+                                        n_random_entities=self.n_random_entities[teacher],
+                                        n_random_relations=self.n_random_relations[teacher], seed=self.seed, device=self.device)
+        return Distillation(teacher_entities=dt.entities, teacher_relations=dt.relations, student_entities=ds.entities,
+                            student_relations=ds.relations, sampling=sampling, device=self.device)
+
+    def forward(self, datasets, models, weight_kl):
+        losses, samples = collections.OrderedDict(), collections.OrderedDict()
+        key = None
+        for key, dataset in datasets.items():
+            data = next(dataset)
+            sample, mode = data["sample"].to(self.device), data["mode"]
+            positive_score = models[key](sample)
+            negative_sample = self.negative_sampling[key].generate(sample=sample, mode=mode).to(self.device)
+            negative_score = models[key](sample, negative_sample, mode=mode)
+            losses[key] = self.loss_function[key](positive_score=positive_score, negative_score=negative_score,
+                                                  weight=data["weight"].to(self.device)) * (1 - weight_kl[key])
+            samples[key] = sample  # the positives are what gets distilled
+        # NB the reference scales every distillation term by weight_kl[<the LAST dataset of the loop above>]
+        # (kdmkb_model.py:348: `weight_kl[id_dataset]` with the stale loop variable); kept, it is what its users train with
+        kl_weight = weight_kl[key]
+        for teacher in datasets:
+            for student in datasets:
+                if teacher != student:
+                    losses[student] = losses[student] + self.distillation[f"{teacher}_{student}"].distill(
+                        teacher=models[teacher], student=models[student], sample=samples[teacher]) * kl_weight
+        for key in datasets:
+            losses[key].backward()
+            self.optimizers[key].step()
+            self.optimizers[key].zero_grad()
+            self.metrics[key].update(losses[key].item())
+        return self.metrics
+
+    def learn(self, models, datasets, max_step, eval_every=2000, update_every=10, log_dir=None, save_path=None):
+        """The reference's outer loop (kdmkb_model.py:362-577) without its pandas / pickle logging: warm-up steps without
+        distillation, then ``alpha_kl``; candidate samplers rebuilt every ``update_distillation_every`` steps; filtered
+        ranking of valid / test every ``eval_every`` steps (printed like ``Pipeline.print_metrics``)."""
+        if log_dir is not None or save_path is not None:
+            raise NotImplementedError("score logging / checkpoint pickling of the reference's learn() is outside the hot path")
+        bar = BarRange(step=max_step, update_every=update_every)
+        for step in bar:
+            weight_kl = {k: 0 for k in datasets} if step < self.warm_step else dict(self.alpha_kl)
+            metrics = self.forward(datasets, models, weight_kl)
+            bar.set_description(text=", ".join(f"{k}: {v.get():4f}" for k, v in metrics.items()))
+            if (step + 1) % self.update_distillation_every == 0:
+                for name in self.distillation:
+                    teacher, student = name.split("_", 1) if name.count("_") == 1 else self._split(name, datasets)
+                    self.distillation[name] = self._make_distillation(models, datasets, teacher, student)
+            if (step + 1) % eval_every == 0:
+                for k, dataset in datasets.items():
+                    models[k] = models[k].eval()
+                    for title, triples in (("Validation:", dataset.valid), ("Test:", dataset.test)):
+                        scores = self.validation[k].eval(model=models[k], dataset=triples)
+                        scores.update(self.validation[k].eval_relations(model=models[k], dataset=triples))
+                        prefix = "valid_" if title.startswith("V") else "test_"
+                        if title.startswith("V"):
+                            print(f"\n Model: {k}, step {step}")
+                        self.print_metrics(description=title, metrics={prefix + m: s for m, s in scores.items()})
+                    models[k] = models[k].train()
+        return self
+
+    @staticmethod
+    def _split(name, datasets):
+        for teacher in datasets:
+            if name.startswith(teacher + "_") and name[len(teacher) + 1:] in datasets:
+                return teacher, name[len(teacher) + 1:]
+        raise KeyError(name)
+
+    @classmethod
+    def print_metrics(cls, description, metrics):
+        print(f"\t {description}")
+        for metric, value in metrics.items():
+            print(f"\t\t {metric}: {value}")

@@ -1,3 +1,4 @@
 from .adversarial import Adversarial
+from .kl_divergence import KlDivergence
 
-__all__ = ["Adversarial"]
+__all__ = ["Adversarial", "KlDivergence"]

@@ -343,6 +343,27 @@ def test_dim_sharded_training_equals_single_device(name, hidden, world):
     assert out.returncode == 0 and "TP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("name,hidden,world", [("RotatE", 24, 2), ("TransE", 33, 3), ("ComplEx", 16, 4)])
+def test_row_sharded_table_training_equals_single_device(name, hidden, world):
+    """BASELINE config 5's partitioning (mkb_amd.table_rows): entity rows, their gradient and their Adam state sharded by
+    row over `world` processes (gloo, all on this one GPU), the fused HIP step running on the compact table of each rank.
+    Losses and reassembled tables must equal the single-process run (tests/tr_worker.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "tr_worker.py"), name, str(hidden), "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
+    assert out.returncode == 0 and "TR_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("name", ["RotatE", "TransE", "ComplEx"])
 @pytest.mark.parametrize("B,K,hidden", [(1, 3, 6), (13, 5, 33), (9, 7, 130)])
 def test_fused_step_edge_shapes_with_wrapping_rows(name, B, K, hidden):

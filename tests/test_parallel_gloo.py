@@ -132,3 +132,99 @@ def test_scores_are_sums_over_dimension_shards():
                 total += closed.pair_scores(model, q, ent[:, ec][neg], head, 0.0, k, 0.7)   # partial: gamma = 0
             c0 = float(np.float32(gamma)) if model in ("TransE", "RotatE", "pRotatE") else 0.0
             np.testing.assert_allclose(total + c0, full, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ row-sharded entity table
+def _table_rows_case(rank, world):
+    """mkb_amd.table_rows (BASELINE config 5's partitioning): entity rows e % world == rank live on
+    ``rank`` together with their gradient and Adam state; pool rows are gathered with one all-reduce, positive rows
+    through an all-to-all; the oracle computes each rank's step on the COMPACT table.  Three steps (head / tail / head)
+    with dense Adam on the shards must reproduce the single-process run on the full table."""
+    from types import SimpleNamespace
+
+    from mkb_amd.table_rows import RowShardedTable, TableRowShardedStep, gather_table_rows
+    from oracle import scoring
+
+    name, N, R, hidden, gamma, alpha = "RotatE", 61, 5, 8, 6.0, 0.5   # 61 rows: uneven shards
+    B, K = 6 * world, 7
+    torch.manual_seed(0)
+    full = scoring.init_tables(name, N, R, hidden, gamma)
+    g = torch.Generator().manual_seed(2)
+
+    def batch():
+        sample = torch.stack([torch.randint(N, (B,), generator=g), torch.randint(R, (B,), generator=g),
+                              torch.randint(N, (B,), generator=g)], 1)
+        pool = torch.randint(N, (2 * K,), generator=g)                       # duplicates allowed, like the reference's pool
+        pos = torch.stack([torch.randperm(2 * K, generator=g)[:K] for _ in range(B)])
+        cnt = torch.zeros(B, 2 * K, dtype=torch.int32).scatter_add_(1, pos, torch.ones_like(pos, dtype=torch.int32))
+        return sample, pool, pos, cnt, torch.rand(B, generator=g) + 0.1
+
+    def oracle_compute(ent, rel, sample, weight, info, mode, weight_sum):
+        tb = scoring.Tables(name, hidden, gamma, ent, rel.detach(), full.modulus)
+        r = scoring.train_step_grads(tb, sample, info.pos.long(), weight, mode, alpha, fast_norm=True)
+        scale = weight.sum() / weight_sum            # global normaliser W (adversarial.py:28-29)
+        return r["loss"] * scale, r["g_ent"] * scale, r["g_rel"] * scale
+
+    table = RowShardedTable.from_full(full.ent)
+    rel = torch.nn.Parameter(full.rel.clone())
+    step = TableRowShardedStep(table, rel, alpha, compute=oracle_compute)
+    ref_ent, ref_rel = full.ent.clone(), full.rel.clone()
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in (("e", ref_ent), ("r", ref_rel))}
+    st_loc = {"e": (torch.zeros_like(table.data), torch.zeros_like(table.data)), "r": (torch.zeros_like(rel), torch.zeros_like(rel))}
+    ok = table.data.shape[0] == len(range(rank, N, world))
+    for it, mode in enumerate(["head-batch", "tail-batch", "head-batch"]):
+        sample, pool, pos, cnt, w = batch()
+        # single process, full table
+        tb = scoring.Tables(name, hidden, gamma, ref_ent, ref_rel, full.modulus)
+        ref = scoring.train_step_grads(tb, sample, pool[pos], w, mode, alpha, fast_norm=True)
+        # this rank's rows of the same global batch
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        neg = pool[pos][lo:hi]
+        neg._mkb_pool = SimpleNamespace(pool=pool, pos=pos[lo:hi].to(torch.int32), cnt=cnt[lo:hi], size=K, mode_id=0)
+        table.data.grad, rel.grad = None, None
+        loss = step(sample[lo:hi], w[lo:hi], neg, mode)
+        ok = ok and torch.allclose(loss, ref["loss"], atol=1e-6)
+        ok = ok and torch.allclose(table.data.grad, ref["g_ent"][rank::world], atol=1e-6)
+        ok = ok and torch.allclose(rel.grad, ref["g_rel"], atol=1e-5)
+        # dense Adam: the full table in one process, the shard here
+        scoring.adam_update(ref_ent, ref["g_ent"], *st["e"], it + 1, lr=1e-2)
+        scoring.adam_update(ref_rel, ref["g_rel"], *st["r"], it + 1, lr=1e-2)
+        with torch.no_grad():
+            scoring.adam_update(table.data, table.data.grad, *st_loc["e"], it + 1, lr=1e-2)
+            scoring.adam_update(rel, rel.grad, *st_loc["r"], it + 1, lr=1e-2)
+        ok = ok and torch.allclose(gather_table_rows(table), ref_ent, atol=1e-6) and torch.allclose(rel.detach(), ref_rel, atol=1e-6)
+    return bool(ok)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_entity_table_equals_single_process(world):
+    assert all(_run(_table_rows_case, world=world))
+
+
+def _private_gather_case(rank, world):
+    from mkb_amd.table_rows import RowShardedTable, gather_table_rows
+
+    torch.manual_seed(3)
+    full = torch.randn(37, 4)
+    t = RowShardedTable.from_full(full)
+    g = torch.Generator().manual_seed(10 + rank)
+    ids = torch.randint(37, (5 + 3 * rank,), generator=g)                 # different counts per rank, duplicates
+    rows, route = t.gather_private(ids)
+    ok = torch.equal(rows, full[ids]) and torch.equal(gather_table_rows(t), full)
+    shared = torch.randint(37, (11,), generator=torch.Generator().manual_seed(99))
+    ok = ok and torch.equal(t.gather_shared(shared), full[shared])
+    grads = torch.randn(ids.numel(), 4, generator=g)
+    t.scatter_add_private(route, grads)
+    want = torch.zeros_like(full)
+    all_ids = [torch.empty(5 + 3 * r, dtype=torch.int64) for r in range(world)]
+    all_g = [torch.empty(5 + 3 * r, 4) for r in range(world)]
+    for r in range(world):  # broadcast every rank's contribution to build the expected dense gradient
+        src_ids, src_g = (ids, grads) if r == rank else (all_ids[r], all_g[r])
+        dist.broadcast(src_ids, src=r)
+        dist.broadcast(src_g, src=r)
+        want.index_add_(0, src_ids, src_g)
+    return bool(ok and torch.allclose(t.data.grad, want[rank::world], atol=1e-6))
+
+
+def test_private_row_gather_and_gradient_return_world3():
+    assert all(_run(_private_gather_case, world=3))

@@ -1,0 +1,72 @@
+"""Worker for tests/test_gpu_pool.py::test_row_sharded_table_training_equals_single_device: launched with
+torch.distributed.run (gloo, every rank on cuda:0).  Every rank owns the entity rows e % world == rank (table, gradient,
+Adam state), runs a few row-sharded steps (mkb_amd.table_rows: pool rows by all-reduce, positive rows by all-to-all, the
+fused HIP step on the compact table), and rank 0 compares the reassembled tables with a single-process run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from mkb_amd import datasets, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+    from mkb_amd.table_rows import TableRowShardedStep, gather_table_rows, shard_table_rows
+
+    name, hidden, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    B = 24 * world
+
+    def batches():
+        g = torch.Generator().manual_seed(9)
+        for i in range(5):
+            idx = torch.randint(len(train), (B,), generator=g).cuda()
+            yield train[idx], (torch.rand(B, generator=g) + 0.1).cuda(), "head-batch" if i % 2 == 0 else "tail-batch"
+
+    def run(sharded):
+        torch.manual_seed(5)
+        full = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=6.0)
+        ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=3)
+        losses = []
+        if sharded:
+            table, rel = shard_table_rows(full, device="cuda")
+            step = TableRowShardedStep(table, rel, 0.5, model_cls=getattr(models, name), hidden_dim=hidden, gamma=6.0)
+            opt = optim.Adam([table.data, rel], lr=2e-3)
+            lo, hi = rank * B // world, (rank + 1) * B // world
+            for s, w, mode in batches():
+                sl = s[lo:hi].contiguous()
+                neg = ns.generate(sl, mode)  # one pool draw per call on every rank: identical pools, own rows filtered
+                losses.append(step(sl, w[lo:hi].contiguous(), neg, mode).item())
+                opt.step()
+                opt.zero_grad()
+            return losses, gather_table_rows(table), rel.detach().clone()
+        model = full.cuda()
+        opt = optim.Adam([model.entity_embedding, model.relation_embedding], lr=2e-3)
+        step = FusedTrainStep(model, 0.5)
+        for s, w, mode in batches():
+            losses.append(step(s, w, ns.generate(s, mode), mode).item())
+            opt.step()
+            opt.zero_grad()
+        return losses, model.entity_embedding.detach(), model.relation_embedding.detach()
+
+    l1, e1, r1 = run(True)
+    if rank == 0:
+        l0, e0, r0 = run(False)
+        np.testing.assert_allclose(l1, l0, rtol=0, atol=3e-5)
+        np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=0, atol=3e-5)
+        np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
+        print("TR_OK", name, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -350,9 +350,91 @@ def gen_headline_slice():
     np.savez_compressed(OUT / "headline_slice.npz", **out)
 
 
+def gen_distill():
+    """Distillation (distillation/distillation.py:438-683, kdmkb_model.py:286-360) captured from the live reference:
+    (a) KlDivergence values + student gradients on random score matrices; (b) Distillation.distill with UniformSampling on
+    Umls RotatE hidden 3 (the reference doctest: loss 1.3066): sampled candidate tensors, loss, student gradients;
+    (c) two partially overlapping toy graphs (only some entities / relations shared); (d) KdmkbModel.forward, 3 steps on two
+    CountriesS1 copies with UniformSampling swapped in for the faiss sampler: per-step losses and final tables."""
+    from mkb import distillation
+    out, js = {}, {}
+    g = torch.Generator().manual_seed(0)
+    for tag, (n, m, T) in {"a": (5, 7, 1.0), "b": (3, 130, 2.5), "c": (1, 2, 0.5)}.items():
+        s = (torch.randn(n, m, generator=g) * 3).requires_grad_(True)
+        t = torch.randn(n, m, generator=g) * 3
+        loss = losses.KlDivergence()(student_score=s, teacher_score=t, T=T)
+        loss.backward()
+        out[f"kl/{tag}/student"], out[f"kl/{tag}/teacher"], out[f"kl/{tag}/T"] = npy(s), npy(t), np.float32(T)
+        out[f"kl/{tag}/loss"], out[f"kl/{tag}/dstudent"] = npy(loss), npy(s.grad)
+
+    # (b) the reference doctest setup
+    torch.manual_seed(42)
+    ds = datasets.Umls(batch_size=3, shuffle=False, seed=42)
+    teacher = models.RotatE(hidden_dim=3, entities=ds.entities, relations=ds.relations, gamma=6)
+    student = models.RotatE(hidden_dim=3, entities=ds.entities, relations=ds.relations, gamma=6)
+    proc = distillation.Distillation(teacher_entities=ds.entities, student_entities=ds.entities, teacher_relations=ds.relations,
+                                     student_relations=ds.relations,
+                                     sampling=distillation.UniformSampling(batch_size_entity=3, batch_size_relation=3, seed=42))
+    data = next(iter(ds))
+    loss = proc.distill(teacher=teacher, student=student, sample=data["sample"])
+    loss.backward()
+    out["umls/teacher_ent"], out["umls/teacher_rel"] = npy(teacher.entity_embedding), npy(teacher.relation_embedding)
+    out["umls/student_ent"], out["umls/student_rel"] = npy(student.entity_embedding), npy(student.relation_embedding)
+    out["umls/sample"], out["umls/loss"] = npy(data["sample"]), npy(loss)
+    out["umls/g_ent"], out["umls/g_rel"] = npy(student.entity_embedding.grad), npy(student.relation_embedding.grad)
+    js["umls_doctest_loss"] = round(float(loss), 4)
+
+    # (c) partial overlap: teacher graph e0..e5 / r0..r2, student graph e3..e8 / r1..r3 (different ids for shared labels)
+    t_ents = {f"e{i}": i for i in range(6)}
+    s_ents = {f"e{i}": j for j, i in enumerate([7, 3, 8, 5, 4, 6])}
+    t_rels = {f"r{i}": i for i in range(3)}
+    s_rels = {"r3": 0, "r1": 1, "r2": 2}
+    torch.manual_seed(7)
+    teacher = models.TransE(hidden_dim=4, entities=t_ents, relations=t_rels, gamma=3)
+    student = models.DistMult(hidden_dim=5, entities=s_ents, relations=s_rels, gamma=3)
+    proc = distillation.Distillation(teacher_entities=t_ents, student_entities=s_ents, teacher_relations=t_rels,
+                                     student_relations=s_rels,
+                                     sampling=distillation.UniformSampling(batch_size_entity=2, batch_size_relation=2, seed=5))
+    sample = torch.tensor([[3, 1, 4], [0, 1, 3], [5, 2, 3], [4, 0, 5], [3, 2, 5]])
+    loss = proc.distill(teacher=teacher, student=student, sample=sample)
+    loss.backward()
+    out["part/teacher_ent"], out["part/teacher_rel"] = npy(teacher.entity_embedding), npy(teacher.relation_embedding)
+    out["part/student_ent"], out["part/student_rel"] = npy(student.entity_embedding), npy(student.relation_embedding)
+    out["part/sample"], out["part/loss"] = npy(sample), npy(loss)
+    out["part/g_ent"], out["part/g_rel"] = npy(student.entity_embedding.grad), npy(student.relation_embedding.grad)
+    js["part_available"] = [proc.available(*row) for row in sample.tolist()]
+
+    # (d) KdmkbModel.forward with the uniform sampler (the reference hard-wires the faiss one: swap the name it looks up)
+    from mkb.distillation import kdmkb_model as km
+    km.FastTopKSampling = distillation.UniformSampling
+    torch.manual_seed(42)
+    d1 = datasets.CountriesS1(batch_size=8, seed=42)
+    d2 = datasets.CountriesS1(batch_size=8, seed=42)
+    m1 = models.TransE(hidden_dim=6, entities=d1.entities, relations=d1.relations, gamma=3)
+    m2 = models.RotatE(hidden_dim=4, entities=d2.entities, relations=d2.relations, gamma=3)
+    out["kd/m1_ent"], out["kd/m1_rel"], out["kd/m2_ent"], out["kd/m2_rel"] = (npy(m1.entity_embedding), npy(m1.relation_embedding),
+                                                                              npy(m2.entity_embedding), npy(m2.relation_embedding))
+    mods, dsets = collections.OrderedDict(a=m1, b=m2), collections.OrderedDict(a=d1, b=d2)
+    kd = km.KdmkbModel(models=mods, datasets=dsets, lr={"a": 1e-2, "b": 1e-2}, alpha_kl={"a": 0.3, "b": 0.6},
+                       alpha_adv={"a": 0.5, "b": 0.5}, negative_sampling_size={"a": 4, "b": 4}, batch_size_entity={"a": 5, "b": 5},
+                       batch_size_relation={"a": 2, "b": 2}, n_random_entities={"a": 3, "b": 3}, n_random_relations={"a": 1, "b": 1},
+                       device="cpu", seed=42)
+    steps = []
+    for step in range(3):
+        w = {"a": 0.3, "b": 0.6}
+        before = {k: kd.metrics[k].get() for k in mods}
+        kd.forward(dsets, mods, w)
+        steps.append({k: kd.metrics[k].w[-1] for k in mods})
+    js["kd_step_losses"] = steps
+    out["kd/m1_ent_after"], out["kd/m2_ent_after"] = npy(m1.entity_embedding), npy(m2.entity_embedding)
+    out["kd/m1_rel_after"], out["kd/m2_rel_after"] = npy(m1.relation_embedding), npy(m2.relation_embedding)
+    np.savez_compressed(OUT / "distill.npz", **out)
+    (OUT / "distill.json").write_text(json.dumps(js, indent=1))
+
+
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["models", "init", "sampler", "weights", "pipeline", "eval", "headline_slice"]
+    which = sys.argv[1:] or ["models", "init", "sampler", "weights", "pipeline", "eval", "headline_slice", "distill"]
     for w in which:
         print("generating", w, file=sys.stderr)
         globals()[f"gen_{w}"]()
