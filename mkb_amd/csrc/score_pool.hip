@@ -93,6 +93,8 @@ struct RowStepArgs {
     // row_bwd inside mkb_pool_step: its last workgroup also finishes the loss (adversarial_finish_block), or nullptr
     const float *loss_rowpart, *loss_scal;
     float *loss_out;
+    // ... and extra workgroups behind the B row workgroups reduce the dx partials of the single-pass backward (blocks > 0)
+    DxReduce dx;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -138,7 +140,13 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
 template <int MODEL, bool HEAD>
 __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     __shared__ float red[4];
-    const int64_t i = blockIdx.x;
+    // rider: dx partial reduction of the pooled backward (one launch fewer per step).  Its workgroups come FIRST: they are
+    // few and heavy (8 partial rows each); dispatched behind the 1024 row workgroups they formed a 30 us tail.
+    if ((int)blockIdx.x < A.dx.blocks) {
+        pool_dx_reduce_block(A.dx, (int)blockIdx.x);
+        return;
+    }
+    const int64_t i = (int64_t)blockIdx.x - A.dx.blocks;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *g_h = A.g_ent + h * A.De, *g_r = A.g_rel + r * A.Dr, *g_t = A.g_ent + t * A.De;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
         extra = block_sum_256_row(extra, red);
         if (threadIdx.x == 0) atomicAdd(A.g_modulus, -extra);
     }
-    if (A.loss_out && blockIdx.x == gridDim.x - 1)  // the per-row loss terms were written by an earlier kernel
+    if (A.loss_out && i == A.B - 1)  // the per-row loss terms were written by an earlier kernel
         adversarial_finish_block(A.loss_rowpart, A.B, A.loss_scal, A.loss_out, red);
 }
 
@@ -381,7 +389,7 @@ static int run_row_fwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
 
 template <int MODEL, bool HEAD>
 static int run_row_bwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
-    hipLaunchKernelGGL((row_bwd_kernel<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL((row_bwd_kernel<MODEL, HEAD>), dim3((unsigned)(B + ra.dx.blocks)), dim3(256), 0, st, ra);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -433,7 +441,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
 
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
                       const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
-                      bool chain_queries = true) {
+                      bool chain_queries = true, DxReduce *dx_out = nullptr) {
     if (use_mfma(tb)) {
         {   // dQ [B, De] = G [B, P] . ent[pool]
             GemmArgs g{};
@@ -453,6 +461,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
         A.g_modulus = gr->g_modulus;
         A.g_ent = gr->g_ent;
+        A.dx_reduce_out = dx_out;
         static const bool split = getenv("MKB_POOL_SPLIT_BWD") != nullptr;  // A/B: the two passes as two launches
         if (L.bwd1) {  // every pair term evaluated once (pool_bwd1_kernel); profiled as the POOL_BWD_Q class
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
@@ -580,7 +589,7 @@ extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, 
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;
     // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
-    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false)) return rc;
+    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr)) return rc;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     return dispatch_row_bwd(tb, head, ra, B, st);
 }

@@ -38,6 +38,8 @@ constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward
 constexpr int kMaxP = 1024; // pool positions supported by the LDS tile lists
 constexpr int kMaxSlices = 8;
 
+struct DxReduce;
+
 struct PoolArgs {
     const float *ent;      // [N, De]
     const float *Q;        // [B, De] queries
@@ -54,6 +56,7 @@ struct PoolArgs {
     int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
     float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
     unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
+    DxReduce *dx_reduce_out;     // host side: non-null = do not launch the reduction, describe it here instead
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 #ifdef MKB_TRACE_WG
@@ -950,44 +953,69 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     MKB_TRACE_OUT(A, 1, tr_t0, tr_t1, tr_t2, 0);
 }
 
-// Sums the row groups' dx partials of one slot and adds them to the slot's table gradient row.  One workgroup per
+// Sums the row groups' dx partials of one slot and adds them to the slot's table gradient row.  One 256-lane workgroup per
 // (block, slot); fixed summation order (row group 0, 1, ...): the only atomics left are the final adds (pool duplicates
-// and the positive triples' rows share gradient rows).
-template <int MODEL, int KPT>
-__global__ __launch_bounds__(256) void pool_dx_reduce_kernel(PoolArgs A, int row_groups) {
-    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
-    constexpr int NC = KPT * (CP ? 2 : 1);
-    typedef typename AccVec<NC>::type acc_t;
-    const int halves = A.pb_halves, cap = halves * 64, npb = A.q_slices;
-    const int pb = blockIdx.x / cap, sidx = blockIdx.x - pb * cap;
+// and the positive triples' rows share gradient rows).  Bandwidth-bound, so kpt / complex layout are run-time values:
+// the body is shared by the stand-alone kernel and by the row backward kernel, whose launch it rides in the fused step.
+struct DxReduce {
+    const float *dXp;
+    const unsigned long long *xused;
+    const int64_t *pool;
+    float *g_ent;
+    int64_t De;
+    int P, d, npb, halves, dim_slices, row_groups, kpt, cplx;
+    int blocks;  // npb * halves * 64
+};
+
+__device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int block) {
+    const int cap = R.halves * 64;
+    const int pb = block / cap, sidx = block - pb * cap;
     const int h = sidx >> 6, l = sidx & 63;
-    const int p = pb + npb * (l * halves + h);
-    if (p >= A.P) return;
+    const int p = pb + R.npb * (l * R.halves + h);
+    if (p >= R.P) return;
     bool any = false;  // did any row group use the slot?
-    for (int rg = 0; rg < row_groups; ++rg) any |= ((A.xused[((size_t)rg * npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
+    for (int rg = 0; rg < R.row_groups; ++rg) any |= ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
     if (!any) return;
-    const int NU = CP ? A.d : (int)A.De;
-    float *row = A.g_ent + A.pool[p] * A.De;
-    const acc_t *in = reinterpret_cast<const acc_t *>(A.dXp);
-    for (int e = threadIdx.x; e < A.dim_slices * 64; e += 256) {  // e = dim slice * 64 + lane
-        const int u0 = e * KPT;
-        if (u0 >= NU) continue;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int rg = 0; rg < row_groups; ++rg) {
-            if (!((A.xused[((size_t)rg * npb + pb) * 8 + h] >> l) & 1ull)) continue;
-            const acc_t v = in[(((size_t)rg * npb + pb) * cap + sidx) * A.dim_slices * 64 + e];
-            if constexpr (NC == 1) a[0] += v;
-            else if constexpr (NC == 2) { a[0] += v.x; a[1] += v.y; }
-            else { a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; }
+    const int nc = R.kpt * (R.cplx ? 2 : 1), NU = R.cplx ? R.d : (int)R.De;
+    float *row = R.g_ent + R.pool[p] * R.De;
+    const int per_slot = R.dim_slices * 64 * nc;  // floats of one slot of one row group
+    if (nc == 4) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
+        for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
+            const int u = e * 2;
+            if (u >= NU) continue;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rg = 0; rg < R.row_groups; ++rg) {
+                if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            atomicAdd(row + u, a.x); atomicAdd(row + u + 1, a.y);
+            atomicAdd(row + R.d + u, a.z); atomicAdd(row + R.d + u + 1, a.w);
         }
-        if constexpr (NC == 1) atomicAdd(row + u0, a[0]);
-        else if constexpr (NC == 2 && !CP) { atomicAdd(row + u0, a[0]); atomicAdd(row + u0 + 1, a[1]); }
-        else if constexpr (NC == 2) { atomicAdd(row + u0, a[0]); atomicAdd(row + A.d + u0, a[1]); }
-        else {
-            atomicAdd(row + u0, a[0]); atomicAdd(row + u0 + 1, a[1]);
-            atomicAdd(row + A.d + u0, a[2]); atomicAdd(row + A.d + u0 + 1, a[3]);
-        }
+        return;
     }
+    for (int f = threadIdx.x; f < per_slot; f += 256) {  // f = (dim slice * 64 + lane) * nc + component
+        const int e = f / nc, c = f - e * nc;
+        const int u = e * R.kpt + (c < R.kpt ? c : c - R.kpt);
+        if (u >= NU) continue;
+        float a = 0.f;
+        for (int rg = 0; rg < R.row_groups; ++rg) {
+            if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
+            a += R.dXp[(((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + f];
+        }
+        atomicAdd(row + (c < R.kpt ? u : R.d + u), a);
+    }
+}
+
+template <int UNUSED = 0>  // (a template so that the header can be included by several translation units)
+__global__ __launch_bounds__(256) void pool_dx_reduce_kernel(DxReduce R) { pool_dx_reduce_block(R, (int)blockIdx.x); }
+
+inline DxReduce make_dx_reduce(const PoolArgs &A, int kpt, bool cplx, int row_groups) {
+    DxReduce R{};
+    R.dXp = A.dXp; R.xused = A.xused; R.pool = A.pool; R.g_ent = A.g_ent; R.De = A.De; R.P = A.P; R.d = A.d;
+    R.npb = A.q_slices; R.halves = A.pb_halves; R.dim_slices = A.dim_slices; R.row_groups = row_groups; R.kpt = kpt;
+    R.cplx = cplx ? 1 : 0; R.blocks = A.q_slices * A.pb_halves * 64;
+    return R;
 }
 
 // ------------------------------------------------------------------------------------------------ launch helpers
@@ -1050,8 +1078,9 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);
     hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT>), dim3(groups * L.q_slices * L.dim_slices),
                        dim3(kBwd1Waves * 64), lds, st, A2);
-    hipLaunchKernelGGL((pool_dx_reduce_kernel<MODEL, KPT>), dim3((unsigned)(L.q_slices * L.pb_halves * 64)), dim3(256), 0, st, A2,
-                       (int)groups);
+    const DxReduce R = make_dx_reduce(A2, KPT, ModelTraits<MODEL>::cplx_pair, (int)groups);
+    if (A.dx_reduce_out) *A.dx_reduce_out = R;  // the caller's next launch (row backward) carries the reduction
+    else hipLaunchKernelGGL(pool_dx_reduce_kernel<0>, dim3((unsigned)R.blocks), dim3(256), 0, st, R);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
