@@ -14,6 +14,8 @@
 // along the CONTIGUOUS index (coalesced 128-B segments) and stored in LDS as [m][k] / [n][k] with a +1 pad so the
 // per-MFMA fragment reads (lane l: row l&31, k = kk + (l>>5)) are bank-conflict free.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mkb {
@@ -136,6 +138,144 @@ __global__ __launch_bounds__(TM * 4) void gemm_f32_mfma_kernel(GemmArgs G) {
     }
 }
 
+// ---- second kernel: 128 x 128 workgroup tile, 2 x 2 MFMA tiles (64 x 64) per wave ---------------------------------------
+// The 64 x 64 kernel above gives a wave 16 MFMAs (1024 cycles) per K chunk against a global-load + LDS round trip of several
+// thousand cycles per chunk: PMC showed the matrix pipe busy 25-30 % of the launch and the waves parked in s_waitcnt /
+// s_barrier 55-60 % of their lifetime.  Here a wave owns four accumulators: 64 MFMAs (4096 cycles) per chunk for twice the
+// staged bytes, fragments are read once per two MFMAs, global loads are 16 bytes wide along the contiguous index, and the
+// next chunk's loads are in flight under the current chunk's MFMAs.  Requires M, N, lda, ldb multiples of 4 (16-byte rows).
+template <bool A_MK, bool B_NK, int EPI>
+__global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
+    constexpr int TM = 128, TN = 128, KC = 32, LD = KC + 1, T = 256;
+    constexpr int V = TM * KC / 4 / T;  // float4 per lane, operand and K chunk (= 4)
+    extern __shared__ __attribute__((aligned(16))) float lds_g[];
+    float *sA = lds_g, *sB = lds_g + TM * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;
+    const int k_lo = blockIdx.z * kper_, k_hi = min(G.K, k_lo + kper_);
+
+    // element e of this lane's share: (row r, first k kk) for k-contiguous operands (float4 along k),
+    //                                  (first row r, k kk) for row-contiguous operands (float4 along m / n)
+    auto coord = [&](bool k_major, int e, int &r, int &kk) {
+        const int f = tid + e * T;                      // float4 index within the 128 x 32 chunk
+        if (k_major) { r = f >> 3; kk = (f & 7) * 4; }  // 8 float4 per row of 32 k
+        else { kk = f >> 5; r = (f & 31) * 4; }         // 32 float4 per k column of 128 rows
+    };
+    // Loads are UNCONDITIONAL from clamped addresses (no select on the loaded value: the compiler turns such a select into a
+    // branch around the load and then waits for the data before the MFMAs).  Rows beyond M / N only feed output rows /
+    // columns that are never stored; k beyond the range is zeroed when the chunk is written to LDS.  Row indirection:
+    // B_NK rows are fixed for the whole K loop (resolved once); B_KN rows change with k: their ids are staged in LDS first
+    // (one dependent global round trip per workgroup instead of one per load).
+    int *s_idx = reinterpret_cast<int *>(lds_g + 2 * TM * LD);  // [kper_] row ids of the K range (B_KN with b_idx)
+    int64_t brow[V];
+    if constexpr (B_NK) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int r, kk;
+            coord(true, e, r, kk);
+            const int64_t sel = min(n0 + r, G.N - 1);
+            brow[e] = (G.b_idx ? G.b_idx[sel] : sel) * G.ldb;
+        }
+    } else if (G.b_idx) {
+        for (int k = k_lo + tid; k < k_hi; k += T) s_idx[k - k_lo] = (int)G.b_idx[k];
+        __syncthreads();
+    }
+    float4 ra[V], rb[V];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int r, kk;
+            coord(A_MK, e, r, kk);
+            const int m = min(m0 + r, G.M - 4), k = min(k0 + kk, A_MK ? k_hi - 4 : k_hi - 1);
+            ra[e] = *reinterpret_cast<const float4 *>(G.A + (A_MK ? (int64_t)m * G.lda + k : (int64_t)k * G.lda + m));
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int r, kk;
+            coord(B_NK, e, r, kk);
+            if constexpr (B_NK) {
+                rb[e] = *reinterpret_cast<const float4 *>(G.B + brow[e] + min(k0 + kk, k_hi - 4));
+            } else {
+                const int k = min(k0 + kk, k_hi - 1), n = min(n0 + r, G.N - 4);
+                const int64_t row = G.b_idx ? (int64_t)s_idx[k - k_lo] : (int64_t)k;
+                rb[e] = *reinterpret_cast<const float4 *>(G.B + row * G.ldb + n);
+            }
+        }
+    };
+    auto store_tiles = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int r, kk;
+            coord(A_MK, e, r, kk);
+            float *d = sA + r * LD + kk;
+            if constexpr (A_MK) {  // float4 along k: zero the part beyond the range
+                d[0] = k0 + kk < k_hi ? ra[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? ra[e].y : 0.f;
+                d[2] = k0 + kk + 2 < k_hi ? ra[e].z : 0.f; d[3] = k0 + kk + 3 < k_hi ? ra[e].w : 0.f;
+            } else {
+                const bool ok = k0 + kk < k_hi;
+                d[0] = ok ? ra[e].x : 0.f; d[LD] = ok ? ra[e].y : 0.f; d[2 * LD] = ok ? ra[e].z : 0.f; d[3 * LD] = ok ? ra[e].w : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int r, kk;
+            coord(B_NK, e, r, kk);
+            float *d = sB + r * LD + kk;
+            if constexpr (B_NK) {
+                d[0] = k0 + kk < k_hi ? rb[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? rb[e].y : 0.f;
+                d[2] = k0 + kk + 2 < k_hi ? rb[e].z : 0.f; d[3] = k0 + kk + 3 < k_hi ? rb[e].w : 0.f;
+            } else {
+                const bool ok = k0 + kk < k_hi;
+                d[0] = ok ? rb[e].x : 0.f; d[LD] = ok ? rb[e].y : 0.f; d[2 * LD] = ok ? rb[e].z : 0.f; d[3 * LD] = ok ? rb[e].w : 0.f;
+            }
+        }
+    };
+
+    if (k_lo < k_hi) load_tiles(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
+        store_tiles(k0);
+        __syncthreads();
+        if (k0 + KC < k_hi) load_tiles(k0 + KC);  // next chunk in flight under this chunk's 64 MFMAs
+        const float *pa = sA + (wm + (lane & 31)) * LD + (lane >> 5);
+        const float *pb = sB + (wn + (lane & 31)) * LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            const float a0 = pa[kk], a1 = pa[32 * LD + kk], b0 = pb[kk], b1 = pb[32 * LD + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *Cz = G.C + (int64_t)blockIdx.z * G.M * G.ldc;  // partial buffer of this K split (z = 0: C itself)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = n0 + wn + 32 * b + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * a + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < G.M && n < G.N) {
+                    const float v = acc[a][b][reg];
+                    if constexpr (EPI == GEMM_STORE) Cz[(int64_t)m * G.ldc + n] = v;
+                    else if constexpr (EPI == GEMM_STORE_AFFINE) Cz[(int64_t)m * G.ldc + n] = (gridDim.z > 1) ? v : G.c0 + G.c1 * v;
+                    else if (v != 0.f) atomicAdd(G.C + G.c_idx[m] * G.ldc + n, v);
+                }
+            }
+        }
+}
+
 // out[i] = c0 + c1 * sum_z part[z][i]   (fixed order: deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t n,
                                                             int nz, float c0, float c1) {
@@ -146,11 +286,64 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
 }
 
+// out[c_idx[m]][n] += sum_z part[z][m][n]: the scattered product goes through split-K partials and ONE atomic per element
+// (pool ids may repeat and the positive triples' rows share gradient rows) instead of one atomic per element and K split.
+__global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                                             const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz) {
+    const int m = blockIdx.x;
+    float *row = out + c_idx[m] * ldc;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < nz; ++z) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + ((int64_t)z * M + m) * N + n);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (a.x != 0.f) atomicAdd(row + n, a.x);
+        if (a.y != 0.f) atomicAdd(row + n + 1, a.y);
+        if (a.z != 0.f) atomicAdd(row + n + 2, a.z);
+        if (a.w != 0.f) atomicAdd(row + n + 3, a.w);
+    }
+}
+
 // These products are small (1-2 GFLOP) and short in one dimension: fill the chip by halving the tile height and / or
 // splitting K (ksplit > 1: STORE epilogues go through `partials` [ksplit, M, ldc] and a fixed-order reduction;
 // the atomic epilogue just accumulates).
 template <bool A_MK, bool B_NK, int EPI>
 static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr) {
+    {   // 128 x 128 tiles (4 accumulators per wave) when the operands allow 16-byte loads and the product is big enough
+        static const bool off = getenv("MKB_GEMM_NO128") != nullptr;  // A/B switch
+        const bool al = (((uintptr_t)G.A | (uintptr_t)G.B) & 15) == 0 && G.lda % 4 == 0 && G.ldb % 4 == 0 && G.M % 4 == 0 &&
+                        G.N % 4 == 0 && G.K % 4 == 0;
+        const int tiles = ((G.M + 127) / 128) * ((G.N + 127) / 128);
+        if (!off && al && tiles >= 24 && (EPI == GEMM_ATOMIC_ROWS || partials)) {
+            int ks = 1;
+            while (tiles * ks < 200 && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
+            G.ksplit = ks;
+            float *final_c = G.C;
+            if (EPI == GEMM_ATOMIC_ROWS && partials) {  // partial products [ks, M, N], then one scattered add per element
+                GemmArgs P2 = G;
+                P2.C = partials; P2.ldc = G.N;
+                const size_t lds2 = (size_t)2 * 128 * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
+                dim3 grid2((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)ks);
+                hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE>), grid2, dim3(256), lds2, st, P2);
+                hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M, G.N,
+                                   G.ldc, ks);
+                MKB_LAUNCH_CHECK();
+                return MKB_OK;
+            }
+            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) G.C = partials;
+            const size_t lds = (size_t)2 * 128 * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
+            dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)ks);
+            hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI>), grid, dim3(256), lds, st, G);
+            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
+                const int64_t n = (int64_t)G.M * G.ldc;
+                const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
+            }
+            MKB_LAUNCH_CHECK();
+            return MKB_OK;
+        }
+    }
     const int tiles64 = ((G.M + 63) / 64) * ((G.N + 63) / 64);
     const bool half = tiles64 < 256;
     const int tiles = half ? ((G.M + 31) / 32) * ((G.N + 63) / 64) : tiles64;

@@ -455,7 +455,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             g.A = w.G; g.lda = P; g.B = w.Q; g.ldb = tb->entity_dim; g.b_idx = nullptr;
             g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
-            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st)) return rc;
+            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part)) return rc;
         }
     } else {
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
