@@ -738,7 +738,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
             MKB_TRACE_ONLY(tr_hand += __builtin_readcyclecounter() - th0;)
-#ifndef MKB_BWD1_NO_FAIR
             // Fair share of the SIMD: the hardware issues oldest-first, which lets the oldest wave of each SIMD run a phase
             // ahead, block on the chain, then the next oldest ... -- the four waves of a SIMD end up running one at a
             // time (per-wave trace: half of every wave's loop time was hand-off wait) and a lone wave cannot fill the VALU.
@@ -751,7 +750,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                                                                                        __HIP_MEMORY_SCOPE_WORKGROUP)));
             if (finished > behind) __builtin_amdgcn_s_setprio(0);
             else __builtin_amdgcn_s_setprio(3);
-#endif
         };
         // The 16 phases of a tile split into RUNS of consecutive phases whose chunks lie in the same half (the seeds and ids
         // of one half fit the lanes).  Inside a run the wave's used positions form one stream, ordered by phase: everything
@@ -872,7 +870,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                     };
 #pragma unroll
                     for (int r = 0; r < TI; r += 2) {
-#ifndef MKB_BWD1_NO_PAIR
                         if constexpr (CP && KPT == 2) {
                             // Rows go two at a time: two interleaved dependent chains fill each other's idle issue slots.  A row
                             // of the pair that does not use the position carries g = 0 and adds exactly 0 (one body per pair
@@ -890,26 +887,17 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                             }
                             continue;
                         }
-#endif
                         if ((__float_as_uint(g[r]) << 1) != 0u) one_row(r);
                         if ((__float_as_uint(g[r + 1]) << 1) != 0u) one_row(r + 1);
                     }
                     // this wave owns the chunk during the phase: plain read-modify-write (read late: 4 VGPRs less across the
                     // rows).  Component order: [re/real KPT][im KPT]
-#ifdef MKB_BWD1_NO_LDS
-                    acc_t upd = acc_t{};
-#else
                     acc_t upd = *slot;
-#endif
                     if constexpr (NC == 1) upd += dx0[0];
                     else if constexpr (NC == 2 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; }
                     else if constexpr (NC == 2) { upd.x += dx0[0]; upd.y += dx1[0]; }
                     else { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx1[0]; upd.w += dx1[1]; }
-#ifdef MKB_BWD1_NO_LDS
-                    if (A.B < 0) *slot = upd;
-#else
                     *slot = upd;
-#endif
                 }
             }
             for (; cur < ph1; ++cur) hand_on(g0 + cur + 1);
@@ -938,9 +926,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     // pool_dx_reduce_kernel sums the row groups and adds the result to the table gradient rows: one fp32 atomic per element
     // instead of one per element AND row group (8.4 M atomics at the headline shape, all issued when the workgroups finish
     // together: 26-37 us of the launch).
-#ifdef MKB_BWD1_NO_FLUSH  // timing experiment only (tools/kbench.py): results are wrong without the flush
-    if (A.B > 0) return;
-#endif
     {
         const size_t wg = (size_t)rg * npb + pb;
         if (s == 0 && tid < 8) A.xused[wg * 8 + tid] = tid < halves ? s_used[tid] : 0ull;
