@@ -144,20 +144,21 @@ __global__ __launch_bounds__(TM * 4) void gemm_f32_mfma_kernel(GemmArgs G) {
 // s_barrier 55-60 % of their lifetime.  Here a wave owns four accumulators: 64 MFMAs (4096 cycles) per chunk for twice the
 // staged bytes, fragments are read once per two MFMAs, global loads are 16 bytes wide along the contiguous index, and the
 // next chunk's loads are in flight under the current chunk's MFMAs.  Requires M, N, lda, ldb multiples of 4 (16-byte rows).
-template <bool A_MK, bool B_NK, int EPI>
+// TN = 128: 2 x 2 MFMA tiles per wave; TN = 64: 2 x 1 (twice the workgroups: products that would otherwise need a K split).
+template <bool A_MK, bool B_NK, int EPI, int TN>
 __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
-    constexpr int TM = 128, TN = 128, KC = 32, LD = KC + 1, T = 256;
-    constexpr int V = TM * KC / 4 / T;  // float4 per lane, operand and K chunk (= 4)
+    constexpr int TM = 128, KC = 32, LD = KC + 1, T = 256, NT = TN / 64;
+    constexpr int V = TM * KC / 4 / T, VB = TN * KC / 4 / T;  // float4 per lane and K chunk: A (= 4), B (= 4 or 2)
     extern __shared__ __attribute__((aligned(16))) float lds_g[];
     float *sA = lds_g, *sB = lds_g + TM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (TN / 2);
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;
@@ -165,23 +166,23 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
 
     // element e of this lane's share: (row r, first k kk) for k-contiguous operands (float4 along k),
     //                                  (first row r, k kk) for row-contiguous operands (float4 along m / n)
-    auto coord = [&](bool k_major, int e, int &r, int &kk) {
-        const int f = tid + e * T;                      // float4 index within the 128 x 32 chunk
+    auto coord = [&](bool k_major, int rows, int e, int &r, int &kk) {
+        const int f = tid + e * T;                      // float4 index within the rows x 32 chunk
         if (k_major) { r = f >> 3; kk = (f & 7) * 4; }  // 8 float4 per row of 32 k
-        else { kk = f >> 5; r = (f & 31) * 4; }         // 32 float4 per k column of 128 rows
+        else { kk = f / (rows / 4); r = (f % (rows / 4)) * 4; }  // rows / 4 float4 per k column
     };
     // Loads are UNCONDITIONAL from clamped addresses (no select on the loaded value: the compiler turns such a select into a
     // branch around the load and then waits for the data before the MFMAs).  Rows beyond M / N only feed output rows /
     // columns that are never stored; k beyond the range is zeroed when the chunk is written to LDS.  Row indirection:
     // B_NK rows are fixed for the whole K loop (resolved once); B_KN rows change with k: their ids are staged in LDS first
     // (one dependent global round trip per workgroup instead of one per load).
-    int *s_idx = reinterpret_cast<int *>(lds_g + 2 * TM * LD);  // [kper_] row ids of the K range (B_KN with b_idx)
-    int64_t brow[V];
+    int *s_idx = reinterpret_cast<int *>(lds_g + (TM + TN) * LD);  // [kper_] row ids of the K range (B_KN with b_idx)
+    int64_t brow[VB];
     if constexpr (B_NK) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
+        for (int e = 0; e < VB; ++e) {
             int r, kk;
-            coord(true, e, r, kk);
+            coord(true, TN, e, r, kk);
             const int64_t sel = min(n0 + r, G.N - 1);
             brow[e] = (G.b_idx ? G.b_idx[sel] : sel) * G.ldb;
         }
@@ -189,19 +190,19 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         for (int k = k_lo + tid; k < k_hi; k += T) s_idx[k - k_lo] = (int)G.b_idx[k];
         __syncthreads();
     }
-    float4 ra[V], rb[V];
+    float4 ra[V], rb[VB];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             int r, kk;
-            coord(A_MK, e, r, kk);
+            coord(A_MK, TM, e, r, kk);
             const int m = min(m0 + r, G.M - 4), k = min(k0 + kk, A_MK ? k_hi - 4 : k_hi - 1);
             ra[e] = *reinterpret_cast<const float4 *>(G.A + (A_MK ? (int64_t)m * G.lda + k : (int64_t)k * G.lda + m));
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
+        for (int e = 0; e < VB; ++e) {
             int r, kk;
-            coord(B_NK, e, r, kk);
+            coord(B_NK, TN, e, r, kk);
             if constexpr (B_NK) {
                 rb[e] = *reinterpret_cast<const float4 *>(G.B + brow[e] + min(k0 + kk, k_hi - 4));
             } else {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             int r, kk;
-            coord(A_MK, e, r, kk);
+            coord(A_MK, TM, e, r, kk);
             float *d = sA + r * LD + kk;
             if constexpr (A_MK) {  // float4 along k: zero the part beyond the range
                 d[0] = k0 + kk < k_hi ? ra[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? ra[e].y : 0.f;
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
             }
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
+        for (int e = 0; e < VB; ++e) {
             int r, kk;
-            coord(B_NK, e, r, kk);
+            coord(B_NK, TN, e, r, kk);
             float *d = sB + r * LD + kk;
             if constexpr (B_NK) {
                 d[0] = k0 + kk < k_hi ? rb[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? rb[e].y : 0.f;
@@ -249,11 +250,14 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         const float *pb = sB + (wn + (lane & 31)) * LD + (lane >> 5);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
-            const float a0 = pa[kk], a1 = pa[32 * LD + kk], b0 = pb[kk], b1 = pb[32 * LD + kk];
+            const float a0 = pa[kk], a1 = pa[32 * LD + kk], b0 = pb[kk];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (NT == 2) {
+                const float b1 = pb[32 * LD + kk];
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NT; ++b) {
             const int n = n0 + wn + 32 * b + (lane & 31);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -310,31 +314,35 @@ __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__rest
 // the atomic epilogue just accumulates).
 template <bool A_MK, bool B_NK, int EPI>
 static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr) {
-    {   // 128 x 128 tiles (4 accumulators per wave) when the operands allow 16-byte loads and the product is big enough
+    {   // 128 x 128 / 128 x 64 tiles (4 / 2 accumulators per wave) when the operands allow 16-byte loads
         static const bool off = getenv("MKB_GEMM_NO128") != nullptr;  // A/B switch
         const bool al = (((uintptr_t)G.A | (uintptr_t)G.B) & 15) == 0 && G.lda % 4 == 0 && G.ldb % 4 == 0 && G.M % 4 == 0 &&
                         G.N % 4 == 0 && G.K % 4 == 0;
-        const int tiles = ((G.M + 127) / 128) * ((G.N + 127) / 128);
-        if (!off && al && tiles >= 24 && (EPI == GEMM_ATOMIC_ROWS || partials)) {
+        const int tiles128 = ((G.M + 127) / 128) * ((G.N + 127) / 128);
+        if (!off && al && tiles128 >= 24 && (EPI == GEMM_ATOMIC_ROWS || partials)) {
+            // fill ~256 CUs: prefer the narrower tile (no K split, no reduction launch) to splitting K
+            const bool narrow = tiles128 < 200;
+            const int tiles = narrow ? ((G.M + 127) / 128) * ((G.N + 63) / 64) : tiles128;
             int ks = 1;
             while (tiles * ks < 200 && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
             G.ksplit = ks;
             float *final_c = G.C;
+            const int tn = narrow ? 64 : 128;
+            const size_t lds = (size_t)(128 + tn) * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
+            dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + tn - 1) / tn), (unsigned)ks);
             if (EPI == GEMM_ATOMIC_ROWS && partials) {  // partial products [ks, M, N], then one scattered add per element
                 GemmArgs P2 = G;
                 P2.C = partials; P2.ldc = G.N;
-                const size_t lds2 = (size_t)2 * 128 * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
-                dim3 grid2((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)ks);
-                hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE>), grid2, dim3(256), lds2, st, P2);
+                if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 64>), grid, dim3(256), lds, st, P2);
+                else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 128>), grid, dim3(256), lds, st, P2);
                 hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M, G.N,
                                    G.ldc, ks);
                 MKB_LAUNCH_CHECK();
                 return MKB_OK;
             }
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) G.C = partials;
-            const size_t lds = (size_t)2 * 128 * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
-            dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + 127) / 128), (unsigned)ks);
-            hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI>), grid, dim3(256), lds, st, G);
+            if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI, 64>), grid, dim3(256), lds, st, G);
+            else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI, 128>), grid, dim3(256), lds, st, G);
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
