@@ -65,6 +65,13 @@ typedef struct {
 int mkb_abi_version(void);
 const char *mkb_last_error(void);
 
+/* Range check of the ids a scoring call is about to use: the reference's index_select (models/base.py:166-207) raises
+ * IndexError for an id outside the table; the kernels index the tables directly, so the glue runs this (one small launch)
+ * on user-supplied ids and raises when it next synchronises.  sample [B, 3], cand [n_cand] (or null); flag: one int32 on
+ * the device, OR-ed with 1 (entity id in sample), 2 (relation id), 4 (candidate id) when something is out of range. */
+int mkb_check_ids(const int64_t *sample, int64_t B, const int64_t *cand, int64_t n_cand, int64_t n_entity,
+                  int64_t n_relation, int32_t *flag, void *stream);
+
 /* ---- general scoring (arbitrary candidate ids) ------------------------------------------------------
  * mkb_score_fwd == model.forward(sample, negative_sample, mode)          (forward of each file under models/)
  *   sample [B,3]; cand [B,K] candidate entity ids (head-batch: heads, tail-batch: tails) or null with

@@ -114,6 +114,8 @@ class Pipeline:
         drain()
         if hasattr(sampling, "check"):
             sampling.check()  # KeyError / empty-filter errors of this epoch's batches (lazy: no per-batch sync)
+        if hasattr(model, "check_ids"):
+            model.check_ids()  # IndexError for ids outside the tables (flagged on the device by the scoring calls)
 
     # ------------------------------------------------------------------ evaluation rounds (pipeline.py:246-321)
     def _score_splits(self, evaluation, model, dataset):

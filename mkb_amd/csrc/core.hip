@@ -70,5 +70,36 @@ extern "C" int mkb_profile_read(int kernel, int64_t *launches, double *total_ms)
     return MKB_OK;
 }
 
+// ---- id range check ---------------------------------------------------------------------------------------------
+namespace mkb {
+__global__ __launch_bounds__(256) void check_ids_kernel(const int64_t *__restrict__ sample, int64_t B, const int64_t *__restrict__ cand,
+                                                        int64_t n_cand, int64_t n_entity, int64_t n_relation, int32_t *__restrict__ flag) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 3 * B + n_cand; i += (int64_t)gridDim.x * 256) {
+        if (i < 3 * B) {
+            const int64_t v = sample[i];
+            const bool rel = i % 3 == 1;
+            if (v < 0 || v >= (rel ? n_relation : n_entity)) bad |= rel ? 2 : 1;
+        } else {
+            const int64_t v = cand[i - 3 * B];
+            if (v < 0 || v >= n_entity) bad |= 4;
+        }
+    }
+    if (bad) atomicOr(flag, bad);
+}
+}  // namespace mkb
+
+extern "C" int mkb_check_ids(const int64_t *sample, int64_t B, const int64_t *cand, int64_t n_cand, int64_t n_entity,
+                             int64_t n_relation, int32_t *flag, void *stream) {
+    MKB_REQUIRE(flag && (sample || B == 0) && (cand || n_cand == 0) && B >= 0 && n_cand >= 0, "bad arguments");
+    const int64_t n = 3 * B + n_cand;
+    if (n == 0) return MKB_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(mkb::check_ids_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sample, B, cand, n_cand, n_entity,
+                       n_relation, flag);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 extern "C" int mkb_abi_version(void) { return MKB_ABI_VERSION; }
 extern "C" const char *mkb_last_error(void) { return mkb::g_err; }

@@ -29,6 +29,10 @@ __all__ = ["BaseModel"]
 # kernels to pay for the scan; set AUTO_POOL = False to always take the general kernels.
 AUTO_POOL = True
 AUTO_POOL_MIN_SLOTS = 32768
+# ``model(sample, negative_sample)`` range-checks user-supplied ids on the device (one small launch, no sync); the result
+# surfaces as IndexError at ``model.check_ids()``.  The fused training step and the evaluation draw their ids from the
+# dataset / the sampler and skip it.
+VALIDATE_IDS = True
 
 
 class _ScoreFn(torch.autograd.Function):
@@ -188,6 +192,8 @@ class BaseModel(Base):
         mode_id = _hip.mode_id(mode)
         sample = _hip.contiguous(sample, torch.int64)
         cand = None
+        if VALIDATE_IDS:
+            self._launch_id_check(sample, negative_sample if mode_id != _hip.MODE_DEFAULT else None)
         if mode_id != _hip.MODE_DEFAULT:
             pooled = getattr(negative_sample, "_mkb_pool", None)
             if (pooled is None and AUTO_POOL and negative_sample.dim() == 2 and negative_sample.shape[1] <= 512
@@ -203,6 +209,34 @@ class BaseModel(Base):
             modulus = self.gamma
         score = _ScoreFn.apply(self.entity_embedding, self.relation_embedding, modulus, self, sample, cand, mode_id)
         return score.view(shape)
+
+    # ------------------------------------------------------------------ id validation
+    def _launch_id_check(self, sample, negative_sample):
+        """One small launch (``mkb_check_ids``) that flags ids outside the tables; nothing is synchronised here.  The
+        reference's ``index_select`` raises IndexError on such ids; the kernels index the tables directly."""
+        dev = self.entity_embedding.device
+        flag = self.__dict__.get("_id_flag")
+        if flag is None or flag.device != dev:
+            flag = self.__dict__["_id_flag"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        cand = None
+        if negative_sample is not None and getattr(negative_sample, "_mkb_pool", None) is None:  # (our sampler's output is trusted)
+            cand = _hip.contiguous(negative_sample, torch.int64)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().mkb_check_ids(_hip.ptr(sample), sample.shape[0], _hip.ptr(cand), 0 if cand is None else cand.numel(),
+                                                self.n_entity, self.n_relation, _hip.ptr(flag), _hip.stream_ptr()), "mkb_check_ids")
+
+    def check_ids(self):
+        """Raise IndexError if any ``model(sample, negative_sample)`` call since the last check used an id outside the
+        tables (synchronises; ``compose.Pipeline`` calls it once per epoch, like ``sampling.check()``)."""
+        flag = self.__dict__.get("_id_flag")
+        if flag is None:
+            return
+        bits = int(flag.item())
+        if bits:
+            flag.zero_()
+            what = [name for bit, name in ((1, "entity id in sample"), (2, "relation id in sample"), (4, "candidate entity id")) if bits & bit]
+            raise IndexError("index out of range in self: " + ", ".join(what)
+                             + f" (tables hold {self.n_entity} entities, {self.n_relation} relations)")
 
     def _set_params(self, entities_embeddings, relations_embeddings, **kwargs):
         """base.py:209-215."""

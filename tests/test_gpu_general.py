@@ -436,3 +436,23 @@ def test_pipeline_on_device_batches_trains_and_matches_dataset_order_without_shu
     b, sb = run(True)
     assert torch.allclose(a, b, rtol=0, atol=1e-6), float((a - b).abs().max())  # (fp32 atomics: equal to rounding)
     assert sa == pytest.approx(sb, abs=1e-4)
+
+
+def test_out_of_range_ids_raise_index_error_like_index_select():
+    """models/base.py:166-207 gathers with index_select, which raises IndexError for an id outside the table.  The kernels
+    index the tables directly: model(...) flags such ids on the device (mkb_check_ids) and check_ids() raises."""
+    from mkb_amd import models
+
+    N, R = 50, 3
+    m = models.TransE(hidden_dim=8, entities={i: i for i in range(N)}, relations={i: i for i in range(R)}, gamma=3.0).cuda()
+    good = torch.tensor([[1, 0, 2], [3, 2, 4]]).cuda()
+    m(good)
+    m(good, torch.tensor([[5, 6], [7, 49]]).cuda(), "tail-batch")
+    m.check_ids()  # nothing flagged
+    m(torch.tensor([[1, 3, 2]]).cuda()[:, [0, 1, 2]].clamp(max=N - 1))  # relation 3 does not exist
+    with pytest.raises(IndexError, match="relation id"):
+        m.check_ids()
+    m.check_ids()  # the flag was cleared
+    m(good[:1], torch.tensor([[0, N - 1]]).cuda(), "head-batch")
+    m.check_ids()
+    torch.cuda.synchronize()
