@@ -47,13 +47,9 @@ class _Patience:
 
 class Pipeline:
     def __init__(self, epochs, eval_every=2000, early_stopping_rounds=3, device="cpu"):
-        self.epochs = epochs
-        self.eval_every = eval_every
-        self.early_stopping_rounds = early_stopping_rounds
-        self.device = device
-        self.metric_loss = RollingMean(1000)
-        self.valid_scores = {}
-        self.test_scores = {}
+        self.epochs, self.eval_every, self.early_stopping_rounds = epochs, eval_every, early_stopping_rounds
+        self.device, self.metric_loss = device, RollingMean(1000)
+        self.valid_scores, self.test_scores = {}, {}
         self.fuse = True  # set False to force the unfused autograd sequence
         # Opt-in: iterate ``datasets.DeviceBatches`` (training triples + weights resident in HBM, batches index-selected on
         # the device) instead of the dataset's two host DataLoaders.  Same batch format, alternation and coverage; the
@@ -93,14 +89,12 @@ class Pipeline:
             if fused is not None:
                 # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
                 error = fused.sampled(sample, weight, sampling, mode)
-            else:
-                score = model(sample)
-                negative_sample = sampling.generate(sample=sample, mode=mode)
-                negative_sample = negative_sample.to(self.device)
-                negative_score = model(sample=sample, negative_sample=negative_sample, mode=mode)
-                error = loss(score, negative_score, weight)
+            else:  # the reference's explicit sequence (pipeline.py:211-236), every call on the HIP kernels
+                positive_score = model(sample)
+                negatives = sampling.generate(sample=sample, mode=mode).to(self.device)
+                error = loss(positive_score, model(sample=sample, negative_sample=negatives, mode=mode), weight)
                 error.backward()
-            _ = optimizer.step()
+            optimizer.step()
             optimizer.zero_grad()
             if fused is not None:
                 # the reference syncs on error.item() every step (pipeline.py:242); the rolling mean only has to be
@@ -109,8 +103,8 @@ class Pipeline:
                 if bar.due() or len(pending) >= 64:
                     drain()
             else:
-                self.metric_loss.update(error.item())
-            bar.set_description(f"Epoch: {epoch}, loss: {self.metric_loss.get():4f}")
+                self.metric_loss.update(float(error.item()))
+            bar.set_description("Epoch: %d, loss: %4f" % (epoch, self.metric_loss.get()))
         drain()
         if hasattr(sampling, "check"):
             sampling.check()  # KeyError / empty-filter errors of this epoch's batches (lazy: no per-batch sync)
@@ -136,21 +130,19 @@ class Pipeline:
             self._run_epoch(epoch, fused, model, dataset, sampling, optimizer, loss)
             if evaluation is None or (epoch + 1) % self.eval_every != 0:
                 continue
-            print(f"\n Epoch: {epoch}.")
+            print("\n Epoch: %d." % epoch)
             self._score_splits(evaluation, model, dataset)
             patience.observe(self.test_scores if dataset.test else self.valid_scores)  # the test split leads when present
             if patience.exhausted:
-                print(f"\n Early stopping at epoch {epoch}.")
-                self.print_metrics(description="Validation:", metrics=self.valid_scores)
-                self.print_metrics(description="Test:", metrics=self.test_scores)
-                return self
-
-        print(f"\n Epoch: {epoch}. \n")
-        self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
+                print("\n Early stopping at epoch %d." % epoch)
+                for title, scores in (("Validation:", self.valid_scores), ("Test:", self.test_scores)):
+                    self.print_metrics(description=title, metrics=scores)
+                break
+        else:
+            print("\n Epoch: %d. \n" % epoch)
+            self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
         return self
 
     @classmethod
     def print_metrics(cls, description, metrics):
-        print(f"\t {description}")
-        for metric, value in metrics.items():
-            print(f"\t\t {metric}: {value}")
+        print("\n".join([f"\t {description}"] + [f"\t\t {name}: {value}" for name, value in metrics.items()]))

@@ -54,11 +54,26 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Layout of the gradient-seed matrix G the single-pass pooled backward reads: log2_blocks < 0 = plain [B, P]; otherwise
+// tile-blocked in the kernel's slot order, G8[tile][block][half][lane][8 rows]: a lane of the backward fetches the 8 seeds of
+// its slot with two 16-byte loads (the plain layout costs it 8 strided 4-byte loads per run).  blocks and halves are powers
+// of two; position p = block + blocks * (lane * halves + half).
+struct SeedLayout {
+    int log2_blocks, log2_halves;
+};
+__host__ __device__ inline int64_t seed_index(const SeedLayout &L, int64_t i, int64_t p, int64_t P) {
+    if (L.log2_blocks < 0) return i * P + p;
+    const int64_t blocks = (int64_t)1 << L.log2_blocks, halves = (int64_t)1 << L.log2_halves;
+    const int64_t pb = p & (blocks - 1), jj = p >> L.log2_blocks;
+    const int64_t h = jj & (halves - 1), l = jj >> L.log2_halves;
+    return (((((i >> 3) << L.log2_blocks) + pb) << L.log2_halves) + h) * 512 + l * 8 + (i & 7);
+}
+
 // loss.hip: Adversarial forward + gradient seeds.  defer_finish: the caller sums scratch[1 .. B] itself with
 // adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
-                       hipStream_t st, bool defer_finish);
+                       hipStream_t st, bool defer_finish, SeedLayout seeds = SeedLayout{-1, 0});
 
 #ifdef __HIPCC__
 // loss = -sum_i rowpart[i] / (2 W) by ONE 256-lane workgroup, fixed order (strided partial sums, wave64 butterfly, then

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
                                                                int B, int K, float alpha, const float *__restrict__ scal,
                                                                float *__restrict__ scal_out, float *__restrict__ dpos,
-                                                               float *__restrict__ dneg, float *__restrict__ rowpart) {
+                                                               float *__restrict__ dneg, float *__restrict__ rowpart, SeedLayout SL) {
     __shared__ float red[4];
     // scal == nullptr: W is reduced here, by every workgroup alike; workgroup 0 publishes it for the finish step
     const float W = scal ? scal[0] : weight_sum_block(w, B, red);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
 #pragma unroll
         for (int t = 0; t < kRowRegs; ++t) {
             const int j = lane + 64 * t;
-            if (j < K) dneg[(int64_t)i * K + j] = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
+            if (j < K) dneg[seed_index(SL, i, j, K)] = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
         }
     } else {
         for (int j = lane; j < K; j += 64) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                 const float vv = nrow[j];
                 g = coef * (cc * fast_exp(alpha * vv - m) * invz) * fast_sigmoid(vv);
             }
-            dneg[(int64_t)i * K + j] = g;
+            dneg[seed_index(SL, i, j, K)] = g;
         }
     }
     if (lane == 0) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__
 
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
-                       hipStream_t st, bool defer_finish) {
+                       hipStream_t st, bool defer_finish, SeedLayout seeds) {
     float *scal = scratch, *rowpart = scratch + 1;
     const float *scal_in = weight_sum;  // W of the whole (sharded) batch when the caller supplies it
     ProfScope ps(MKB_PROF_LOSS, st);
@@ -156,7 +156,7 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
         scal_in = scal;
     }
     hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart);
+                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds);
     if (!defer_finish)
         hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B,
                            weight_sum ? weight_sum : scal, loss);

@@ -212,9 +212,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
 }
 
 __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restrict__ src, const uint16_t *__restrict__ cnt,
-                                                          float *__restrict__ dst, int64_t n) {
+                                                          float *__restrict__ dst, int64_t n, int64_t P, SeedLayout SL) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = cnt[i] ? src[i] : 0.f;
+    if (i < n) dst[seed_index(SL, i / P, i % P, P)] = cnt[i] ? src[i] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -321,7 +321,10 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     auto take = [&](size_t n) { void *r = p ? p + off : nullptr; off += align256(n); return (float *)r; };
     w.Q = take((size_t)B * De * 4);
     w.dQ = take((size_t)L.q_slices * B * De * 4);
-    w.G = take((size_t)B * P * 4);
+    // gradient seeds: plain [B, P], or the tile-blocked layout of the single-pass backward (rows padded to tiles of 8,
+    // positions to blocks * halves * 64 slots)
+    const size_t g_plain = (size_t)B * P, g_blocked = L.bwd1 ? (size_t)((B + 7) / 8) * L.q_slices * L.pb_halves * 64 * 8 : 0;
+    w.G = take((g_plain > g_blocked ? g_plain : g_blocked) * 4);
     w.dpos = take((size_t)B * 4);
     w.scratch = take((size_t)(B + 1) * 4);
     w.gemm_part = take(L.mfma ? (size_t)8 * B * (P > De ? P : De) * 4 : 0);  // split-K partials of the MFMA path
@@ -339,6 +342,12 @@ static int g_trace_kind = 2;
 extern "C" void mkb_debug_set_trace(void *p, int kind) { g_trace = (unsigned long long *)p; g_trace_kind = kind; }
 #endif
 
+static SeedLayout seed_layout(const PoolLaunch &L) {
+    if (!L.bwd1) return SeedLayout{-1, 0};
+    auto lg = [](int v) { int b = 0; while ((1 << b) < v) ++b; return b; };
+    return SeedLayout{lg(L.q_slices), lg(L.pb_halves)};
+}
+
 static PoolArgs make_args(const mkb_tables_t *tb, const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t P,
                           const Workspace &w, const PoolLaunch &L) {
     PoolArgs A{};
@@ -346,6 +355,7 @@ static PoolArgs make_args(const mkb_tables_t *tb, const int64_t *pool, const uin
     A.B = (int)B; A.P = (int)P; A.d = tb->hidden_dim; A.De = tb->entity_dim; A.kd = tb->phase_div;
     A.modulus = tb->modulus; A.x_slices = L.x_slices; A.q_slices = L.q_slices;
     A.dXp = w.dXp; A.xused = w.xused;
+    A.g_blocked = L.bwd1 ? 1 : 0;
     const bool g = tb->model == MKB_TRANSE || tb->model == MKB_ROTATE || tb->model == MKB_PROTATE;
     A.c0 = g ? tb->gamma : 0.f;
     A.c1 = g ? -1.f : 1.f;
@@ -539,7 +549,7 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
     if (int rc = dispatch_query_build(tb, mode_is_head(mode), ra, B, st)) return rc;
     // G = caller's gradient with the entries no row uses forced to 0 (the single-pass backward reads the mask off G)
     hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((B * 2 * K + 255) / 256)), dim3(256), 0, st, dpool_score, cnt, w.G,
-                       B * 2 * K);
+                       B * 2 * K, 2 * K, seed_layout(L));
     MKB_LAUNCH_CHECK();
     return pooled_bwd(tb, mode_is_head(mode), gr, sample, pool, cnt, B, 2 * K, w, L, st);
 }
@@ -584,7 +594,7 @@ extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, 
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
-                                    /*defer_finish=*/true)) return rc;
+                                    /*defer_finish=*/true, seed_layout(L))) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;

@@ -57,6 +57,7 @@ struct PoolArgs {
     float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
     unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
     DxReduce *dx_reduce_out;     // host side: non-null = do not launch the reduction, describe it here instead
+    int g_blocked;               // G is in the tile-blocked seed layout of common.h (SeedLayout of this launch's blocks / halves)
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 #ifdef MKB_TRACE_WG
@@ -770,9 +771,15 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 const int p_own = pb + npb * (lane * halves + h);
                 const bool valid = p_own < A.P;
                 unsigned nz = 0, pm = 0;
+                if (A.g_blocked) {  // the lane's 8 seeds are contiguous: two 16-byte loads
+                    const float4 *gp = reinterpret_cast<const float4 *>(A.G + ((((int64_t)tile * npb + pb) * halves + h) * 64 + lane) * 8);
+                    const float4 ga = gp[0], gb = gp[1];
+                    gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gb.x; gv[5] = gb.y; gv[6] = gb.z; gv[7] = gb.w;
+                }
 #pragma unroll
                 for (int r = 0; r < TI; ++r) {
-                    gv[r] = (valid && i0 + r < A.B) ? A.G[(int64_t)(i0 + r) * A.P + p_own] : 0.f;
+                    if (A.g_blocked) gv[r] = (valid && i0 + r < A.B) ? gv[r] : 0.f;
+                    else gv[r] = (valid && i0 + r < A.B) ? A.G[(int64_t)(i0 + r) * A.P + p_own] : 0.f;
                     const unsigned u = __float_as_uint(gv[r]) << 1;  // +-0 -> unused pair (the loss kernel writes 0 for them)
                     nz |= u;
                     pm |= u ? (0x10000u << (r >> 1)) : 0u;

@@ -47,19 +47,17 @@ class Dataset:
         self.classification_valid, self.classification_test = classification_valid, classification_test
         self.train, self.valid, self.test = train, valid, test
 
-        self.entities = entities
-        if entities is None:
-            self.entities = self.mapping_entities()
-            self._map_splits(lambda h, r, t: (self.entities[h], r, self.entities[t]))
-        self.relations = relations
-        if relations is None:
-            self.relations = self.mapping_relations()
-            self._map_splits(lambda h, r, t: (h, self.relations[r], t))
+        # label -> id maps: taken as given, or built from the triples (which are then relabelled)
+        for kind, given, relabel in (("entities", entities, lambda ids, h, r, t: (ids[h], r, ids[t])),
+                                     ("relations", relations, lambda ids, h, r, t: (h, ids[r], t))):
+            ids = getattr(self, f"mapping_{kind}")() if given is None else given
+            setattr(self, kind, ids)
+            if given is None:
+                self._map_splits(lambda h, r, t, ids=ids, relabel=relabel: relabel(ids, h, r, t))
         self.n_entity, self.n_relation = len(self.entities), len(self.relations)
 
         self._loaders = {mode: self.get_train_loader(mode=mode) for mode in _VIEWS}
-        self.len = int(sum(len(loader.dataset) for loader in self._loaders.values()) / batch_size)
-        self.step = 0
+        self.len, self.step = int(sum(len(loader.dataset) for loader in self._loaders.values()) / batch_size), 0
         self._streams = {mode: self.fetch(loader) for mode, loader in self._loaders.items()}
 
         if seed:  # 0 / None leave the global generator alone, like the reference
@@ -77,9 +75,7 @@ class Dataset:
         """train + valid + test as one fresh list (absent splits skipped)."""
         return [triple for name in _SPLITS for triple in (getattr(self, name) or ())]
 
-    @property
-    def train_triples(self):
-        return self.train
+    train_triples = property(lambda self: self.train)
 
     def mapping_entities(self):
         known = self.true_triples
@@ -116,18 +112,17 @@ class Dataset:
         return itertools.chain.from_iterable(zip(*(self._loaders[mode] for mode in _VIEWS)))
 
     def __next__(self):
-        self.step += 1
-        return next(self._streams[_VIEWS[self.step % 2]])  # odd steps: tail-batch, even steps: head-batch
+        self.step = step = self.step + 1
+        return next(self._streams[_VIEWS[step % 2]])  # odd steps: tail-batch, even steps: head-batch
 
     @staticmethod
     def fetch(dataloader):
         """Endless stream of batches: a new pass over ``dataloader`` starts whenever one ends."""
-        while True:
-            for batch in dataloader:
-                yield batch
+        for _ in itertools.count():
+            yield from dataloader
 
     def __len__(self):
-        return self.len
+        return int(self.len)
 
     # ------------------------------------------------------------------ evaluation views
     def _get_test_loader(self, triples, batch_size, mode):
@@ -139,19 +134,14 @@ class Dataset:
         return [self._get_test_loader(triples=triples, batch_size=batch_size, mode=mode) for mode in _VIEWS]
 
     def test_dataset(self, batch_size):
-        return self.test_stream(triples=self.test, batch_size=batch_size)
+        return self.test_stream(self.test, batch_size)
 
     def validation_dataset(self, batch_size):
-        return self.test_stream(triples=self.valid, batch_size=batch_size)
+        return self.test_stream(self.valid, batch_size)
 
     # ------------------------------------------------------------------ display
-    @property
-    def name(self):
-        return type(self).__name__
-
-    @property
-    def _repr_title(self):
-        return f"{self.name} dataset"
+    name = property(lambda self: type(self).__name__)
+    _repr_title = property(lambda self: self.name + " dataset")
 
     @property
     def _repr_content(self):
