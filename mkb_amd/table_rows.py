@@ -149,6 +149,7 @@ class TableRowShardedStep:
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
         self._work = {}
+        self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
 
     # -- default compute: the fused pooled step (mkb_pool_step) on a working model that holds the compact table
     def _working_model(self, n_rows, device):
@@ -160,6 +161,8 @@ class TableRowShardedStep:
             m.relation_embedding = self.relation  # the replicated table itself: its .grad is the relation gradient
             if self._modulus is not None:
                 m.modulus = self._modulus
+            elif self._trains_modulus:
+                raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")
             self._work[n_rows] = m
         return m
 
@@ -198,11 +201,19 @@ class TableRowShardedStep:
         if self.compute is None:
             if rel.grad is None:
                 rel.grad = torch.zeros_like(rel)
+        mod = self._modulus if (self.compute is None and self._trains_modulus) else None
+        mod_before = None if mod is None or mod.grad is None else mod.grad.clone()
         loss, g_ent, g_rel = run(ent, rel, compact, weight, info, mode, w_sum)      # 3
-        # 4: pool-row gradients + relation gradient + loss share in ONE all-reduce
-        buf = torch.cat([g_ent[:P].reshape(-1), g_rel.reshape(-1), loss.reshape(1).to(g_ent.dtype)])
+        # 4: pool-row gradients + relation gradient (+ pRotatE's modulus gradient) + loss share in ONE all-reduce
+        parts = [g_ent[:P].reshape(-1), g_rel.reshape(-1)]
+        if mod is not None:
+            g_mod = (mod.grad if mod_before is None else mod.grad - mod_before).reshape(-1).clone()
+            parts.append(g_mod)
+        buf = torch.cat(parts + [loss.reshape(1).to(g_ent.dtype)])
         if self.world > 1:
             dist.all_reduce(buf, group=self.group)
+        if mod is not None:  # replicated scalar: replace this rank's share by the sum
+            mod.grad.add_((buf[-2:-1] - g_mod).view_as(mod.grad))
         n_pool = P * tb.dim
         tb.scatter_add_shared(info.pool, buf[:n_pool].view(P, tb.dim))
         g_rel_sum = buf[n_pool: n_pool + rel.numel()].view_as(rel)

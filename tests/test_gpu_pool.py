@@ -343,7 +343,7 @@ def test_dim_sharded_training_equals_single_device(name, hidden, world):
     assert out.returncode == 0 and "TP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("name,hidden,world", [("RotatE", 24, 2), ("TransE", 33, 3), ("ComplEx", 16, 4)])
+@pytest.mark.parametrize("name,hidden,world", [("RotatE", 24, 2), ("TransE", 33, 3), ("ComplEx", 16, 4), ("pRotatE", 20, 2)])
 def test_row_sharded_table_training_equals_single_device(name, hidden, world):
     """BASELINE config 5's partitioning (mkb_amd.table_rows): entity rows, their gradient and their Adam state sharded by
     row over `world` processes (gloo, all on this one GPU), the fused HIP step running on the compact table of each rank.

@@ -38,8 +38,10 @@ def main():
         losses = []
         if sharded:
             table, rel = shard_table_rows(full, device="cuda")
-            step = TableRowShardedStep(table, rel, 0.5, model_cls=getattr(models, name), hidden_dim=hidden, gamma=6.0)
-            opt = optim.Adam([table.data, rel], lr=2e-3)
+            mod = torch.nn.Parameter(full.modulus.detach().clone().cuda()) if name == "pRotatE" else None
+            step = TableRowShardedStep(table, rel, 0.5, model_cls=getattr(models, name), hidden_dim=hidden, gamma=6.0,
+                                       modulus=mod)
+            opt = optim.Adam([table.data, rel] + ([mod] if mod is not None else []), lr=2e-3)
             lo, hi = rank * B // world, (rank + 1) * B // world
             for s, w, mode in batches():
                 sl = s[lo:hi].contiguous()
@@ -47,19 +49,25 @@ def main():
                 losses.append(step(sl, w[lo:hi].contiguous(), neg, mode).item())
                 opt.step()
                 opt.zero_grad()
-            return losses, gather_table_rows(table), rel.detach().clone()
+            return losses, gather_table_rows(table), rel.detach().clone(), None if mod is None else mod.detach().clone()
         model = full.cuda()
-        opt = optim.Adam([model.entity_embedding, model.relation_embedding], lr=2e-3)
+        opt = optim.Adam([model.entity_embedding, model.relation_embedding] + ([model.modulus] if name == "pRotatE" else []),
+                         lr=2e-3)
         step = FusedTrainStep(model, 0.5)
         for s, w, mode in batches():
             losses.append(step(s, w, ns.generate(s, mode), mode).item())
             opt.step()
             opt.zero_grad()
-        return losses, model.entity_embedding.detach(), model.relation_embedding.detach()
+        return losses, model.entity_embedding.detach(), model.relation_embedding.detach(), \
+            (model.modulus.detach() if name == "pRotatE" else None)
 
-    l1, e1, r1 = run(True)
+    l1, e1, r1, m1 = run(True)
     if rank == 0:
-        l0, e0, r0 = run(False)
+        l0, e0, r0, m0 = run(False)
+        if m0 is not None:  # the replicated trainable modulus took the same steps
+            assert float(m0) != float(getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations,
+                                                            gamma=6.0).modulus)
+            np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=0, atol=3e-5)
         np.testing.assert_allclose(l1, l0, rtol=0, atol=3e-5)
         np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=0, atol=3e-5)
         np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
