@@ -146,36 +146,38 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
 #define MKB_CATCH_THREADS 1024
 #endif
 constexpr int kCatchThreads = MKB_CATCH_THREADS;
-__device__ __forceinline__ void replay_row(const AdamRowArgs &A, int64_t row, int from, int to) {
+__device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int64_t k, float (&pp)[2], float (&mm)[2],
+                                            float (&vv)[2]) {
+    const float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
+    if (k + 2 <= A.D && (A.D & 1) == 0) {  // (rows are 8-byte aligned when D is even; an odd D ends on a single element)
+        const float2 a = *reinterpret_cast<const float2 *>(p + k), b = *reinterpret_cast<const float2 *>(m + k),
+                     c = *reinterpret_cast<const float2 *>(v + k);
+        pp[0] = a.x; pp[1] = a.y; mm[0] = b.x; mm[1] = b.y; vv[0] = c.x; vv[1] = c.y;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = k + e < A.D;
+            pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, float (&pp)[2],
+                                              float (&mm)[2], float (&vv)[2]) {
     float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
-    for (int64_t k = (int64_t)threadIdx.x * 2; k < A.D; k += 2 * kCatchThreads) {
-        const bool vec = k + 2 <= A.D;  // (rows are 8-byte aligned when D is even; an odd D ends on a single element)
-        float pp[2], mm[2], vv[2];
-        if (vec && (A.D & 1) == 0) {
-            const float2 a = *reinterpret_cast<const float2 *>(p + k), b = *reinterpret_cast<const float2 *>(m + k),
-                         c = *reinterpret_cast<const float2 *>(v + k);
-            pp[0] = a.x; pp[1] = a.y; mm[0] = b.x; mm[1] = b.y; vv[0] = c.x; vv[1] = c.y;
-        } else {
+    for (int s = from + 1; s <= to; ++s) {
+        const float2 c = A.consts[s];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const bool ok = k + e < A.D;
-                pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
-            }
-        }
-        for (int s = from + 1; s <= to; ++s) {
-            const float2 c = A.consts[s];
+        for (int e = 0; e < 2; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
+    }
+    if (k + 2 <= A.D && (A.D & 1) == 0) {
+        *reinterpret_cast<float2 *>(p + k) = make_float2(pp[0], pp[1]);
+        *reinterpret_cast<float2 *>(m + k) = make_float2(mm[0], mm[1]);
+        *reinterpret_cast<float2 *>(v + k) = make_float2(vv[0], vv[1]);
+    } else {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
-        }
-        if (vec && (A.D & 1) == 0) {
-            *reinterpret_cast<float2 *>(p + k) = make_float2(pp[0], pp[1]);
-            *reinterpret_cast<float2 *>(m + k) = make_float2(mm[0], mm[1]);
-            *reinterpret_cast<float2 *>(v + k) = make_float2(vv[0], vv[1]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
-        }
+        for (int e = 0; e < 2; ++e)
+            if (k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
     }
 }
 
@@ -198,10 +200,19 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
                                                         : A.seg_sample[3 * (bid - A.seg_P - A.seg_B) + 2]);
     else row = bid;
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
+    // the row's first elements are requested BEFORE the exchange returns (a global atomic round trip ahead of the row's
+    // HBM latency otherwise); workgroups that turn out to have nothing to do drop them
+    const int64_t k0 = (int64_t)threadIdx.x * 2;
+    float pp[2], mm[2], vv[2];
+    const bool ahead = A.ids || A.seg_pool;  // (a flush walks every row, most of them with nothing pending: no guessing there)
+    if (ahead && k0 < A.D) replay_load(A, row, k0, pp, mm, vv);
     __syncthreads();
     const int old = s_old;
     if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
-    replay_row(A, row, old, A.step);
+    for (int64_t k = k0; k < A.D; k += 2 * kCatchThreads) {
+        if (!ahead || k != k0) replay_load(A, row, k, pp, mm, vv);
+        replay_finish(A, row, k, old, A.step, pp, mm, vv);
+    }
 }
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
@@ -216,14 +227,21 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     if (bid == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
     const int64_t row = A.ids[bid];
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
-    __syncthreads();
-    if (s_old == A.step) return;  // duplicate id: another workgroup owns this row
     float *p = A.p + row * A.D, *g = A.g + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
     if ((A.D & 3) == 0) {  // 16-byte aligned rows: one float4 per lane and array
         float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g);
         float4 *m4 = reinterpret_cast<float4 *>(m), *v4 = reinterpret_cast<float4 *>(v);
-        for (int64_t k = threadIdx.x; k < (A.D >> 2); k += 256) {
-            float4 pp = p4[k], gg = g4[k], mm = m4[k], vv = v4[k];
+        // the first float4s are requested BEFORE the ownership exchange returns (a global atomic round trip): a duplicate's
+        // workgroup wastes four cached loads, every owner saves that latency
+        const int64_t k0 = threadIdx.x, n4 = A.D >> 2;
+        float4 pp0, gg0, mm0, vv0;
+        if (k0 < n4) { pp0 = p4[k0]; gg0 = g4[k0]; mm0 = m4[k0]; vv0 = v4[k0]; }
+        __syncthreads();
+        if (s_old == A.step) return;  // duplicate id: another workgroup owns this row
+        for (int64_t k = k0; k < n4; k += 256) {
+            float4 pp, gg, mm, vv;
+            if (k == k0) { pp = pp0; gg = gg0; mm = mm0; vv = vv0; }
+            else { pp = p4[k]; gg = g4[k]; mm = m4[k]; vv = v4[k]; }
             adam_one(pp.x, gg.x, mm.x, vv.x, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
             adam_one(pp.y, gg.y, mm.y, vv.y, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
             adam_one(pp.z, gg.z, mm.z, vv.z, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
@@ -232,6 +250,8 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
         }
         return;
     }
+    __syncthreads();
+    if (s_old == A.step) return;
     for (int64_t k = threadIdx.x; k < A.D; k += 256) {
         float pp = p[k], mm = m[k], vv = v[k];
         adam_one(pp, g[k], mm, vv, A.w1, A.b2, A.w2, A.neg_step, A.sqrt_bc2, A.eps);
