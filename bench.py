@@ -94,7 +94,9 @@ def build(device, rank, world, seed=42, parallelism="dims"):
         step = TableRowShardedStep(table, rel_rep, ALPHA, model_cls=getattr(models, MODEL), hidden_dim=HIDDEN, gamma=GAMMA)
     else:
         opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
-                         lr=LR, lazy_rows=lazy, draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None)
+                         lr=LR, lazy_rows=lazy, draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None,
+                         # what compose.Pipeline configures for its fused loop (MKB_BENCH_NO_DEFER=1: the separate step launch)
+                         defer_step=os.environ.get("MKB_BENCH_NO_DEFER", "0") != "1")
         step = parallel.DimShardedStep(model, ALPHA) if dims else FusedTrainStep(model, ALPHA)
     train = torch.as_tensor(train_np, device=device)
     weights = subsampling_weights(train_np).to(device)

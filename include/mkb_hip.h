@@ -204,6 +204,24 @@ typedef struct {
 int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                        int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr, float beta1,
                        float beta2, float eps, const mkb_adam_dense_t *rider, void *stream);
+/* "Advance" form of mkb_adam_rows_catchup / _catchup_generate: the real step of the touched rows is deferred too.  The rows
+ * of step t's batch were made current through t-1 before its forward pass, so after backward their state is "current
+ * through t-1, gradient of step t in the gradient row" -- and stays that way until the row is next read: the replay takes
+ * the row's gradient row for its FIRST pending step (zero for rows that were not touched then, which is the
+ * zero-gradient step bit for bit) and clears it.  mkb_adam_rows_step is then only needed for the very first step
+ * (`last` = 0 means "never touched").  grad: the table's dense gradient [n_rows, D]; lr: learning rate of step
+ * step_upto (recorded into consts[step_upto] by the launch); rider: the small dense tensor that takes ITS step
+ * (rider->step) in the same launch, or null.  Callers must bring a row current (catch-up / advance) BEFORE a backward
+ * pass writes its gradient row, and route every read of the tables through an advance with ids = null (flush). */
+int mkb_adam_rows_advance(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                          int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float lr,
+                          float beta1, float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead,
+                          void *stream);
+int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                   int64_t n_rows, int64_t D, int64_t step_upto, float lr, float beta1, float beta2, float eps,
+                                   const mkb_adam_dense_t *rider, mkb_sampler_t *sampler, const int64_t *sample, int64_t B,
+                                   int mode, int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
+                                   void *stream);
 
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the

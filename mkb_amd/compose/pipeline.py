@@ -65,6 +65,9 @@ class Pipeline:
             return None
         if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "draw_ahead", "x") is None:
             optimizer.draw_ahead = sampling  # mkb_amd.optim.Adam: the next pool's draw rides the catch-up launch
+        if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "defer_step", "x") is None:
+            optimizer.defer_step = True  # this loop clears gradients through optimizer.zero_grad() only: the real step of
+            #                              the touched rows may wait for the next catch-up launch (mkb_amd/optim.py)
         return FusedTrainStep(model, loss.alpha)
 
     def _run_epoch(self, epoch, fused, model, dataset, sampling, optimizer, loss):

@@ -99,6 +99,13 @@ extern "C" int mkb_adam_step(float *param, float *grad, float *exp_avg, float *e
 // everything that is pending (before evaluation, checkpointing, or any direct read of the table).
 // Rows that were never touched have m = v = 0, for which a dense step is the identity: they are skipped.
 // consts[s] = (-lr / (1 - beta1^s), sqrt(1 - beta2^s)) is recorded by the step kernel for later replays.
+//
+// "Advance" form (mkb_adam_rows_advance*): the REAL step is deferred as well.  A row the batch of step t touched was made
+// current through t-1 before the forward pass, so after backward it is the one row state "current through t-1, gradient of
+// step t in its gradient row".  Nothing forces that step to be applied before the row is next read: the replay of a row
+// simply takes the row's gradient for its FIRST pending step (a zero row for rows that were not touched then: adam_one at
+// g = 0 is the zero-gradient step, bit for bit) and clears it.  The separate step launch (a second pass over p, m, v of
+// every touched row) disappears; the small dense tensor that rode it rides the next advance launch instead.
 
 namespace mkb {
 
@@ -124,6 +131,9 @@ struct AdamRowArgs {
     FilterArgs filt;
     const int64_t *seg_pool, *seg_sample;
     int32_t seg_P, seg_B;
+    // advance form (catch-up kernel with g != null): a row's first replayed step takes its gradient row; step `step`
+    // uses (neg_step, sqrt_bc2) from here (recorded into consts[step] by the launch), n_ids = number of row blocks,
+    // the dense rider (dp ...) is stepped by the blocks behind them
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -147,43 +157,68 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
 #endif
 constexpr int kCatchThreads = MKB_CATCH_THREADS;
 __device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int64_t k, float (&pp)[2], float (&mm)[2],
-                                            float (&vv)[2]) {
+                                            float (&vv)[2], float (&gg)[2]) {
     const float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
+    gg[0] = gg[1] = 0.f;
     if (k + 2 <= A.D && (A.D & 1) == 0) {  // (rows are 8-byte aligned when D is even; an odd D ends on a single element)
         const float2 a = *reinterpret_cast<const float2 *>(p + k), b = *reinterpret_cast<const float2 *>(m + k),
                      c = *reinterpret_cast<const float2 *>(v + k);
         pp[0] = a.x; pp[1] = a.y; mm[0] = b.x; mm[1] = b.y; vv[0] = c.x; vv[1] = c.y;
+        if (A.g) {
+            const float2 d = *reinterpret_cast<const float2 *>(A.g + row * A.D + k);
+            gg[0] = d.x; gg[1] = d.y;
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const bool ok = k + e < A.D;
             pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+            if (A.g && ok) gg[e] = A.g[row * A.D + k + e];
         }
     }
 }
 
+__device__ __forceinline__ float2 replay_consts(const AdamRowArgs &A, int s) {
+    // advance form: consts[A.step] is being written by this very launch -- take it from the arguments
+    return (A.g && s == A.step) ? make_float2(A.neg_step, A.sqrt_bc2) : A.consts[s];
+}
+
 __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, float (&pp)[2],
-                                              float (&mm)[2], float (&vv)[2]) {
+                                              float (&mm)[2], float (&vv)[2], float (&gg)[2]) {
     float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
-    for (int s = from + 1; s <= to; ++s) {
-        const float2 c = A.consts[s];
+    int s = from + 1;
+    if (A.g) {  // the row's first pending step is the one its gradient row belongs to
+        const float2 c = replay_consts(A, s);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) adam_one(pp[e], gg[e], mm[e], vv[e], A.w1, A.b2, A.w2, c.x, c.y, A.eps);
+        ++s;
+    }
+    for (; s <= to; ++s) {
+        const float2 c = replay_consts(A, s);
 #pragma unroll
         for (int e = 0; e < 2; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
     }
+    const bool clear = A.g && (gg[0] != 0.f || gg[1] != 0.f);
     if (k + 2 <= A.D && (A.D & 1) == 0) {
         *reinterpret_cast<float2 *>(p + k) = make_float2(pp[0], pp[1]);
         *reinterpret_cast<float2 *>(m + k) = make_float2(mm[0], mm[1]);
         *reinterpret_cast<float2 *>(v + k) = make_float2(vv[0], vv[1]);
+        if (clear) *reinterpret_cast<float2 *>(A.g + row * A.D + k) = make_float2(0.f, 0.f);
     } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-            if (k + e < A.D) { p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e]; }
+            if (k + e < A.D) {
+                p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e];
+                if (clear) A.g[row * A.D + k + e] = 0.f;
+            }
     }
 }
 
 __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
     __shared__ int s_old;
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_draw[];  // only sized when a draw block rides
+    if (A.g && A.step > 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);  // advance form: the launch after a deferred step records it
     if (A.first_row_block && blockIdx.x == 0) {  // dispatched first: ~8 us of serial work in the shadow of the row blocks
         pool_draw_body<kCatchThreads>(A.draw, lds_draw);
         return;
@@ -193,6 +228,12 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
         return;
     }
     const int64_t bid = (int64_t)blockIdx.x - A.first_row_block - A.n_filter;
+    if (bid >= A.n_ids) {  // the dense rider of a deferred step: the last blocks
+        const int64_t nb = (int64_t)gridDim.x - A.first_row_block - A.n_filter - A.n_ids;
+        adam_dense_range(A.dp, A.dg, A.dm, A.dv, A.dn, (bid - A.n_ids) * kCatchThreads + threadIdx.x, nb * kCatchThreads, A.w1,
+                         A.b2, A.w2, A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
+        return;
+    }
     int64_t row;
     if (A.ids) row = A.ids[bid];
     else if (A.seg_pool) row = bid < A.seg_P ? A.seg_pool[bid]
@@ -203,15 +244,15 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
     // the row's first elements are requested BEFORE the exchange returns (a global atomic round trip ahead of the row's
     // HBM latency otherwise); workgroups that turn out to have nothing to do drop them
     const int64_t k0 = (int64_t)threadIdx.x * 2;
-    float pp[2], mm[2], vv[2];
+    float pp[2], mm[2], vv[2], gg[2];
     const bool ahead = A.ids || A.seg_pool;  // (a flush walks every row, most of them with nothing pending: no guessing there)
-    if (ahead && k0 < A.D) replay_load(A, row, k0, pp, mm, vv);
+    if (ahead && k0 < A.D) replay_load(A, row, k0, pp, mm, vv, gg);
     __syncthreads();
     const int old = s_old;
     if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
     for (int64_t k = k0; k < A.D; k += 2 * kCatchThreads) {
-        if (!ahead || k != k0) replay_load(A, row, k, pp, mm, vv);
-        replay_finish(A, row, k, old, A.step, pp, mm, vv);
+        if (!ahead || k != k0) replay_load(A, row, k, pp, mm, vv, gg);
+        replay_finish(A, row, k, old, A.step, pp, mm, vv, gg);
     }
 }
 
@@ -274,21 +315,83 @@ static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float 
 
 }  // namespace mkb
 
-extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
-                                     int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto,
-                                     float beta1, float beta2, float eps, mkb_sampler_t *draw_ahead, void *stream) {
-    mkb::AdamRowArgs A{};
-    if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, 0.f, beta1, beta2, eps)) return rc;
-    const int64_t n = ids ? n_ids : n_rows;
-    if (n <= 0 || step_upto <= 0) return MKB_OK;
+namespace mkb {
+
+// dense rider of an advance launch -> number of extra workgroups (0 = none)
+static int attach_rider(AdamRowArgs &A, const mkb_adam_dense_t *rider, float lr, float beta1, float beta2, int threads,
+                        int64_t *extra) {
+    *extra = 0;
+    if (!rider || rider->n <= 0) return MKB_OK;
+    MKB_REQUIRE(rider->param && rider->grad && rider->exp_avg && rider->exp_avg_sq && rider->step >= 1, "bad dense rider");
+    MKB_REQUIRE((((uintptr_t)rider->param | (uintptr_t)rider->grad | (uintptr_t)rider->exp_avg | (uintptr_t)rider->exp_avg_sq) & 15) == 0,
+                "buffers must be 16-byte aligned");
+    A.dp = rider->param; A.dg = rider->grad; A.dm = rider->exp_avg; A.dv = rider->exp_avg_sq; A.dn = rider->n;
+    A.d_neg_step = (float)(-((double)lr / (1.0 - pow((double)beta1, (double)rider->step))));
+    A.d_sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)rider->step));
+    int64_t e = ((rider->n >> 2) + threads - 1) / threads;
+    *extra = e < 1 ? 1 : (e > 1024 ? 1024 : e);
+    return MKB_OK;
+}
+
+static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                        int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float lr, float beta1,
+                        float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead, void *stream) {
+    AdamRowArgs A{};
+    if (int rc = fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, lr, beta1, beta2, eps)) return rc;
+    int64_t n = ids ? n_ids : n_rows;
+    if (n <= 0 || step_upto <= 0) n = 0;  // nothing can be pending before the first step
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
+    A.n_ids = (int32_t)n;
+    int64_t extra = 0;
+    if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
+    if (n + extra == 0) return MKB_OK;
     size_t lds = 0;
-    if (draw_ahead && mkb::sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
-    mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(n + A.first_row_block)), dim3(mkb::kCatchThreads), lds,
+    if (draw_ahead && ids && sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
+    ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
+    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(n + extra + A.first_row_block)), dim3(kCatchThreads), lds,
                        (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
+}
+
+static int rows_advance_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                 int64_t D, int64_t step_upto, float lr, float beta1, float beta2, float eps,
+                                 const mkb_adam_dense_t *rider, mkb_sampler_t *sampler, const int64_t *sample, int64_t B,
+                                 int mode, int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
+                                 void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AdamRowArgs A{};
+    if (int rc = fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, nullptr, D, step_upto > 0 ? step_upto : 0, lr,
+                           beta1, beta2, eps)) return rc;
+    size_t lds = 0;
+    ProfScope ps(MKB_PROF_SAMPLER, st);
+    if (int rc = sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
+        return rc;
+    A.first_row_block = 1;
+    A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
+    A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
+    const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
+    A.n_ids = (int32_t)rows;
+    int64_t extra = 0;
+    if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
+    static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)
+    if (!big_lds) {
+        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&adam_rows_catchup_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows + extra)), dim3(kCatchThreads), lds, st, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+}  // namespace mkb
+
+extern "C" int mkb_adam_rows_catchup(float *param, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                     int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto,
+                                     float beta1, float beta2, float eps, mkb_sampler_t *draw_ahead, void *stream) {
+    return mkb::rows_advance(param, nullptr, exp_avg, exp_avg_sq, last, consts, n_rows, D, ids, n_ids, step_upto, 0.f, beta1,
+                             beta2, eps, nullptr, draw_ahead, stream);
 }
 
 // mkb_sampler_generate and mkb_adam_rows_catchup(ids = the batch's pool | heads | tails) as ONE launch, plus the draw of
@@ -298,27 +401,31 @@ extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, floa
                                               mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
                                               int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
     (void)n_rows;
-    hipStream_t st = (hipStream_t)stream;
-    mkb::AdamRowArgs A{};
-    if (int rc = mkb::fill_args(A, param, nullptr, exp_avg, exp_avg_sq, last, consts, nullptr, D, step_upto > 0 ? step_upto : 0, 0.f,
-                                beta1, beta2, eps)) return rc;
-    size_t lds = 0;
-    mkb::ProfScope ps(MKB_PROF_SAMPLER, st);
-    if (int rc = mkb::sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
-        return rc;
-    A.first_row_block = 1;
-    A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
-    A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
-    const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
-    static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)
-    if (!big_lds) {
-        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mkb::adam_rows_catchup_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        big_lds = true;
-    }
-    hipLaunchKernelGGL(mkb::adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows)), dim3(mkb::kCatchThreads), lds, st, A);
-    MKB_LAUNCH_CHECK();
-    return MKB_OK;
+    return mkb::rows_advance_generate(param, nullptr, exp_avg, exp_avg_sq, last, consts, D, step_upto, 0.f, beta1, beta2, eps,
+                                      nullptr, sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream);
+}
+
+// Advance form of the two calls above (see the top of the row-lazy section): `grad` = the table's dense gradient, whose
+// rows the replay consumes (first pending step of each row) and clears; `lr` = learning rate of step `step_upto` (the
+// step whose own launch was skipped); rider = the small dense tensor of that step, or null.
+extern "C" int mkb_adam_rows_advance(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                     int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float lr,
+                                     float beta1, float beta2, float eps, const mkb_adam_dense_t *rider,
+                                     mkb_sampler_t *draw_ahead, void *stream) {
+    MKB_REQUIRE(grad, "null gradient (use mkb_adam_rows_catchup)");
+    return mkb::rows_advance(param, grad, exp_avg, exp_avg_sq, last, consts, n_rows, D, ids, n_ids, step_upto, lr, beta1, beta2,
+                             eps, rider, draw_ahead, stream);
+}
+
+extern "C" int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last,
+                                              float *consts, int64_t n_rows, int64_t D, int64_t step_upto, float lr, float beta1,
+                                              float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *sampler,
+                                              const int64_t *sample, int64_t B, int mode, int64_t *neg, int64_t *pool,
+                                              int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
+    (void)n_rows;
+    MKB_REQUIRE(grad, "null gradient (use mkb_adam_rows_catchup_generate)");
+    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, D, step_upto, lr, beta1, beta2, eps, rider,
+                                      sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream);
 }
 
 extern "C" int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,

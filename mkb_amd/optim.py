@@ -14,6 +14,16 @@ brought up to date before the forward pass and take the real step afterwards; ev
 it is next needed or at ``flush()`` (``compose.Pipeline`` / ``evaluation`` / ``model(...)`` outside the fused
 step / ``model.embeddings`` / ``model.save`` flush automatically; flush by hand before reading
 ``model.entity_embedding`` directly).
+
+``defer_step=True`` (``compose.Pipeline`` turns it on for its fused loop) defers the REAL step of the touched rows as
+well: after backward such a row is "current through t-1, gradient of step t in its ``.grad`` row", and the next
+catch-up / flush that visits it replays step t WITH that gradient (then clears it) -- ``step()`` launches nothing, and
+the second pass over p / m / v of every touched row (``mkb_adam_rows_step``) disappears.  Same arithmetic in the same
+order: still bit-identical to dense Adam after ``flush()``.  The small dense parameters that rode the step launch (the
+relation table) ride the next catch-up launch instead, so with ``defer_step`` they too are only current after
+``flush()``.  Contract: clear gradients through ``optimizer.zero_grad()`` only (``model.zero_grad()`` /
+``p.grad.zero_()`` would erase a step that has not been applied yet), and let every backward pass that writes the
+table's gradient be preceded by ``catch_up`` of its rows (``FusedTrainStep`` / ``parallel.DimShardedStep`` do).
 """
 import torch
 
@@ -23,7 +33,7 @@ __all__ = ["Adam"]
 
 
 class Adam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False, draw_ahead=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False, draw_ahead=None, defer_step=None):
         """``draw_ahead``: a ``mkb_amd.sampling.NegativeSampling`` whose NEXT pool draw should ride the row catch-up
         launch of each step (one kernel launch and ~13 us of serial latency fewer per training step; the negatives are
         the same, bit for bit).  Only meaningful with ``lazy_rows=True`` and a sampler on the same device / stream."""
@@ -33,6 +43,8 @@ class Adam:
         self.state = {}
         self.step_count = 0
         self.lazy_rows = lazy_rows
+        self.defer_step = defer_step  # None: off until compose.Pipeline (or the caller) turns it on; False: never
+        self._pending_dense = None    # (parameter, AdamDense, lr, gradient tensor kept alive) of a deferred step
         self._zeroed = False
         if lazy_rows:
             for p in self.params:
@@ -58,6 +70,14 @@ class Adam:
         return c
 
     # ------------------------------------------------------------------ lazy rows
+    def _take_dense(self):
+        """The dense rider of the last deferred step (or None): it joins the launch that is about to be made."""
+        pend, self._pending_dense = self._pending_dense, None
+        return None if pend is None else pend[1]
+
+    def _lr_of(self, st, step):
+        return st.get("lrs", {}).get(step, self.lr)
+
     def catch_up(self, p, ids, upto=None):
         """Make the rows ``ids`` of ``p`` current through step ``upto`` (default: every step taken so far)."""
         st = self._state(p)
@@ -66,29 +86,78 @@ class Adam:
             return
         ids = _hip.contiguous(ids, torch.int64)
         st["caught_up"] = (ids, upto)
+        lib, c = _hip.lib(), self._consts(st, upto)
         with torch.cuda.device(p.device):
-            _hip.check(_hip.lib().mkb_adam_rows_catchup(_hip.ptr(p.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
-                                                        _hip.ptr(st["last"]), _hip.ptr(self._consts(st, upto)), p.shape[0],
-                                                        p.shape[1], _hip.ptr(ids), ids.numel(), upto, self.betas[0],
-                                                        self.betas[1], self.eps, self._sampler_handle(p.device),
-                                                        _hip.stream_ptr()),
-                       "mkb_adam_rows_catchup")
+            if st.get("defer"):
+                _hip.check(lib.mkb_adam_rows_advance(_hip.ptr(p.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                     _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1], _hip.ptr(ids),
+                                                     ids.numel(), upto, self._lr_of(st, upto), self.betas[0], self.betas[1],
+                                                     self.eps, self._take_dense(), self._sampler_handle(p.device),
+                                                     _hip.stream_ptr()), "mkb_adam_rows_advance")
+            else:
+                _hip.check(lib.mkb_adam_rows_catchup(_hip.ptr(p.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                     _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1], _hip.ptr(ids),
+                                                     ids.numel(), upto, self.betas[0], self.betas[1], self.eps,
+                                                     self._sampler_handle(p.device), _hip.stream_ptr()),
+                           "mkb_adam_rows_catchup")
+
+    def catch_up_generate(self, p, sampler_handle, sample, B, mode_id, neg, pool, pos, cnt, touched):
+        """``catch_up(p, rows of this batch)`` fused with the sampler's filter + next-pool draw (one launch; see
+        ``sampling.NegativeSampling.generate_with_catch_up``)."""
+        st = self._state(p)
+        upto = st["n"]
+        lib, c = _hip.lib(), self._consts(st, max(upto, 1))
+        tail = (sampler_handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg), _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt),
+                _hip.ptr(touched), _hip.stream_ptr())
+        with torch.cuda.device(p.device):
+            if st.get("defer"):
+                _hip.check(lib.mkb_adam_rows_advance_generate(
+                    _hip.ptr(p.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]), _hip.ptr(c),
+                    p.shape[0], p.shape[1], upto, self._lr_of(st, upto), self.betas[0], self.betas[1], self.eps,
+                    self._take_dense(), *tail), "mkb_adam_rows_advance_generate")
+            else:
+                _hip.check(lib.mkb_adam_rows_catchup_generate(
+                    _hip.ptr(p.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0],
+                    p.shape[1], upto, self.betas[0], self.betas[1], self.eps, *tail), "mkb_adam_rows_catchup_generate")
+        st["caught_up"] = (touched, upto)
 
     def flush(self, p=None):
-        """Replay every pending zero-gradient step: afterwards the tables equal what dense Adam would hold."""
+        """Replay everything that is pending: afterwards the tables equal what dense Adam would hold."""
+        lib = _hip.lib()
         for q in ([p] if p is not None else self.params):
             if _links.owner(q) is not self:
                 continue
             st = self._state(q)
             if st["n"] <= 0 or st.get("flushed") == st["n"]:
                 continue
+            c = self._consts(st, st["n"])
             with torch.cuda.device(q.device):
-                _hip.check(_hip.lib().mkb_adam_rows_catchup(_hip.ptr(q.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
-                                                            _hip.ptr(st["last"]), _hip.ptr(self._consts(st, st["n"])),
-                                                            q.shape[0], q.shape[1], None, 0, st["n"], self.betas[0],
-                                                            self.betas[1], self.eps, None, _hip.stream_ptr()),
-                           "mkb_adam_rows_catchup")
+                if st.get("defer"):
+                    _hip.check(lib.mkb_adam_rows_advance(_hip.ptr(q.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]),
+                                                         _hip.ptr(st["v"]), _hip.ptr(st["last"]), _hip.ptr(c), q.shape[0],
+                                                         q.shape[1], None, 0, st["n"], self._lr_of(st, st["n"]), self.betas[0],
+                                                         self.betas[1], self.eps, self._take_dense(), None, _hip.stream_ptr()),
+                               "mkb_adam_rows_advance")
+                else:
+                    _hip.check(lib.mkb_adam_rows_catchup(_hip.ptr(q.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                         _hip.ptr(st["last"]), _hip.ptr(c), q.shape[0], q.shape[1], None, 0,
+                                                         st["n"], self.betas[0], self.betas[1], self.eps, None,
+                                                         _hip.stream_ptr()), "mkb_adam_rows_catchup")
             st["flushed"] = st["n"]
+        pend, self._pending_dense = self._pending_dense, None
+        if pend is not None:  # no launch above carried it (its table was already flushed): step it on its own
+            q, d, lr, _ = pend
+            with torch.cuda.device(q.device):
+                _hip.check(lib.mkb_adam_step(d.param, d.grad, d.exp_avg, d.exp_avg_sq, d.n, d.step, lr, self.betas[0],
+                                             self.betas[1], self.eps, 1, _hip.stream_ptr()), "mkb_adam_step")
+
+    def stop_deferring(self):
+        """Apply whatever ``defer_step`` left pending and switch it off for good (callers whose gradient rows are not
+        preceded by a catch-up, e.g. ``parallel.SparseGradExchange``)."""
+        self.flush()
+        self.defer_step = False
+        for st in self.state.values():
+            st.pop("defer", None)
 
     # ------------------------------------------------------------------ torch.optim-like API
     def _rider(self):
@@ -131,10 +200,26 @@ class Adam:
             touched = _links.take_touched(p) if _links.owner(p) is self else None
             with torch.cuda.device(p.device):
                 if touched is not None:
+                    done = st.get("caught_up")
+                    caught = done is not None and done[1] == st["n"]  # a catch-up at this step count preceded the gradient
+                    if self.defer_step and st["n"] >= 1 and caught:
+                        # deferred: the rows were current through n before their gradient was written; the next catch-up /
+                        # flush that visits a row replays this step with its gradient row (nothing is launched here)
+                        st["n"] += 1
+                        st["defer"], st["g"] = True, g
+                        lrs = st.setdefault("lrs", {})
+                        lrs[st["n"]] = self.lr
+                        lrs.pop(st["n"] - 4, None)
+                        if rider_p is not None:
+                            self._pending_dense = (rider_p, rider, self.lr, rider_p.grad)
+                        continue
+                    if st.get("defer") and not caught:
+                        raise RuntimeError("mkb_amd.optim.Adam(defer_step=True): gradient rows were written without a catch-up of "
+                                           "those rows in this step, so they cannot be told from a step that is still pending; "
+                                           "call optimizer.stop_deferring() before training this way")
                     st["n"] += 1
                     ids = _hip.contiguous(touched, torch.int64)
                     c = self._consts(st, st["n"])
-                    done = st.get("caught_up")
                     if done is None or done[0] is not touched or done[1] != st["n"] - 1:
                         self.catch_up(p, ids, upto=st["n"] - 1)  # e.g. rows only OTHER data-parallel ranks touched
                     _hip.check(lib.mkb_adam_rows_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
@@ -158,6 +243,8 @@ class Adam:
         if self._zeroed and not set_to_none:
             self._zeroed = False
             return
+        if any(st.get("defer") for st in self.state.values()):
+            self.flush()  # a deferred step lives in the gradient rows: apply it before they are really cleared
         for p in self.params:
             if p.grad is not None:
                 if set_to_none:
@@ -198,6 +285,9 @@ class Adam:
             st["n"] = int(saved["step"])
             st.pop("caught_up", None)
             st["flushed"] = st["n"]
+            if st.pop("defer", None):  # nothing is pending in a restored state
+                st["g"].zero_()
             if "last" in st:  # row-lazy: nothing is pending, the replay constants of earlier steps are not needed again
                 st["last"].fill_(st["n"])
+        self._pending_dense = None
         self._zeroed = False

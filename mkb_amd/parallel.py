@@ -91,6 +91,11 @@ class SparseGradExchange:
         self.model, self.group, self.equal_batches = model, group, equal_batches
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.last_rows_moved = 0
+        opt = _links.owner(model.entity_embedding)
+        if opt is not None and hasattr(opt, "stop_deferring"):
+            # rows only OTHER ranks touched receive their gradient here without a catch-up before it: the optimizer's
+            # deferred real step (which reads "gradient row = the row's first pending step") cannot be used
+            opt.stop_deferring()
 
     def weight_sum(self, weight):
         w = weight.sum().reshape(1)

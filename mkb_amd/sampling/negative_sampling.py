@@ -181,15 +181,7 @@ class NegativeSampling:
         cnt = torch.empty((B, 2 * K), dtype=torch.uint16, device=dev)
         touched = torch.empty(2 * K + 2 * B, dtype=torch.int64, device=dev)
         mode_id = _hip.mode_id(mode)
-        st = optimizer._state(param)
-        upto = st["n"]
-        with torch.cuda.device(dev):
-            _hip.check(_hip.lib().mkb_adam_rows_catchup_generate(
-                _hip.ptr(param.data), _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
-                _hip.ptr(optimizer._consts(st, max(upto, 1))), param.shape[0], param.shape[1], upto, optimizer.betas[0],
-                optimizer.betas[1], optimizer.eps, self._handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg), _hip.ptr(pool),
-                _hip.ptr(pos), _hip.ptr(cnt), _hip.ptr(touched), _hip.stream_ptr()), "mkb_adam_rows_catchup_generate")
-        st["caught_up"] = (touched, upto)
+        optimizer.catch_up_generate(param, self._handle, sample, B, mode_id, neg, pool, pos, cnt, touched)
         neg._mkb_pool = PoolInfo(pool, pos, cnt, K, mode_id, sample)
         neg._mkb_pool.touched = touched
         return neg

@@ -1,0 +1,193 @@
+"""``mkb_amd.optim.Adam(lazy_rows=True, defer_step=True)``: the real step of the touched rows waits in their gradient rows
+until the next catch-up / flush visits them (mkb_adam_rows_advance*, mkb_amd/csrc/adam.hip).  Same arithmetic in the
+same order as the separate step launch, so everything here is compared BIT FOR BIT against ``defer_step=False`` wherever
+the gradients themselves are deterministic, and against dense Adam."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(seed=5, n=5000, d=64, r=37):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ent = torch.nn.Parameter(torch.randn(n, d, generator=g).cuda())  # >= 4096 rows: steps row-lazily
+    rel = torch.nn.Parameter(torch.randn(r, d, generator=g).cuda())  # small: dense, rides the row launch
+    ent.grad, rel.grad = torch.zeros_like(ent), torch.zeros_like(rel)
+    return ent, rel
+
+
+def _synthetic_steps(opt, ent, rel, steps, seed=11, on_step=None):
+    """Hand-made gradients through the optimizer's own protocol: catch-up of the rows, THEN their gradient, then step."""
+    from mkb_amd import _links
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for it in steps:
+        ids = torch.randint(ent.shape[0], (300,), generator=g).cuda()  # with duplicates, like a batch's pool | heads | tails
+        vals = torch.randn(300, ent.shape[1], generator=g).cuda()
+        relg = torch.randn(rel.shape, generator=g).cuda()
+        if it == 5:
+            opt.lr = 3e-3  # a scheduler changing the rate: the deferred step must use the rate of ITS step
+        opt.catch_up(ent, ids)
+        uniq = torch.unique(ids)
+        ent.grad[uniq] += vals[: uniq.numel()]  # one deterministic value per distinct row
+        rel.grad += relg
+        _links.mark_touched(ent, ids)
+        opt.step()
+        opt.zero_grad()
+        if on_step is not None:
+            on_step(it)
+
+
+@pytest.mark.parametrize("d", [64, 33])
+def test_deferred_step_equals_separate_step_launch_bit_for_bit(d):
+    from mkb_amd import optim
+
+    out = []
+    for defer in (True, False):
+        ent, rel = _tables(d=d)
+        opt = optim.Adam([ent, rel], lr=1e-2, lazy_rows=True, defer_step=defer)
+        mids = []
+
+        def peek(it):
+            if it == 7:  # an evaluation in the middle of training: flush, read, carry on
+                opt.flush()
+                mids.append((ent.detach().clone(), rel.detach().clone()))
+
+        _synthetic_steps(opt, ent, rel, range(12), on_step=peek)
+        if defer:
+            assert opt.state[ent].get("defer") and ent.grad.any(), "the last step should still be waiting in the gradient rows"
+        opt.flush()
+        assert not ent.grad.any() and not rel.grad.any()
+        st = opt.state[ent]
+        out.append((mids[0][0], mids[0][1], ent.detach().clone(), rel.detach().clone(), st["m"].clone(), st["v"].clone(),
+                    opt.state[rel]["m"].clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    # ... and dense Adam on the same gradients (torch.optim.Adam, a few ulp of the update)
+    ent, rel = _tables(d=d)
+    ref = torch.optim.Adam([ent, rel], lr=1e-2)
+
+    class Dense:  # the protocol of _synthetic_steps on top of torch.optim
+        lr = 1e-2
+
+        def catch_up(self, *a): pass
+
+        def step(self):
+            for grp in ref.param_groups:
+                grp["lr"] = self.lr
+            ref.step()
+
+        def zero_grad(self):
+            ent.grad.zero_(); rel.grad.zero_()
+
+    _synthetic_steps(Dense(), ent, rel, range(12))
+    np.testing.assert_allclose(out[0][2].cpu().numpy(), ent.detach().cpu().numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(out[0][3].cpu().numpy(), rel.detach().cpu().numpy(), rtol=0, atol=3e-6)
+
+
+def test_deferred_step_survives_set_to_none_and_checkpoint_resume():
+    from mkb_amd import optim
+
+    def run(defer, resume_at=None):
+        ent, rel = _tables()
+        opt = optim.Adam([ent, rel], lr=1e-2, lazy_rows=True, defer_step=defer)
+        _synthetic_steps(opt, ent, rel, range(4))
+        opt.zero_grad(set_to_none=True)  # really clears: whatever is waiting must be applied first
+        assert ent.grad is None
+        ent.grad, rel.grad = torch.zeros_like(ent), torch.zeros_like(rel)
+        _synthetic_steps(opt, ent, rel, range(4, 8), seed=12)
+        if resume_at is not None:
+            sd = opt.state_dict()  # flushes
+            e2, r2 = _tables()
+            with torch.no_grad():
+                e2.copy_(ent); r2.copy_(rel)
+            opt2 = optim.Adam([e2, r2], lr=1e-2, lazy_rows=True, defer_step=defer)
+            opt2.load_state_dict(sd)
+            ent, rel, opt = e2, r2, opt2
+        _synthetic_steps(opt, ent, rel, range(8, 12), seed=13)
+        opt.flush()
+        return ent.detach().clone(), rel.detach().clone()
+
+    want = run(False)
+    for got in (run(True), run(True, resume_at=8)):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def test_gradient_rows_without_catch_up_are_refused_when_deferring():
+    from mkb_amd import _links, optim
+
+    ent, rel = _tables()
+    opt = optim.Adam([ent, rel], lr=1e-2, lazy_rows=True, defer_step=True)
+    _synthetic_steps(opt, ent, rel, range(3))
+    ids = torch.arange(10, device="cuda")
+    ent.grad[ids] += 1.0          # no catch-up of these rows in this step
+    _links.mark_touched(ent, ids)
+    with pytest.raises(RuntimeError, match="stop_deferring"):
+        opt.step()
+
+
+def test_fused_training_with_deferred_step_matches_the_separate_launch():
+    """The whole fused loop (sampler riding the catch-up, gradient accumulation, a plain ``model(...)`` call and an
+    evaluation in between, which flush) with and without ``defer_step``; the gradients come from fp32 atomics, so the
+    two runs agree to rounding."""
+    from mkb_amd import models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    N, R = 5000, 4
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(1)
+    train = np.stack([rs.randint(N, size=3000), rs.randint(R, size=3000), rs.randint(N, size=3000)], 1)
+    t = torch.as_tensor(train).cuda()
+    w = torch.ones(32, device="cuda")
+
+    def run(defer, name):
+        torch.manual_seed(3)
+        m = getattr(models, name)(hidden_dim=16, entities=ents, relations=rels, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=16, train_triples=train, entities=ents, relations=rels, seed=1)
+        params = [m.entity_embedding, m.relation_embedding] + ([m.modulus] if name == "pRotatE" else [])
+        opt = optim.Adam(params, lr=1e-2, lazy_rows=True, draw_ahead=ns, defer_step=defer)
+        step = FusedTrainStep(m, 1.0)
+        probes = []
+        for it in range(10):
+            mode = "tail-batch" if it % 2 else "head-batch"
+            for half in range(2 if it in (3, 4) else 1):  # steps 3 and 4 accumulate two backward passes
+                s = t[(2 * it + half) * 32: (2 * it + half + 1) * 32].contiguous()
+                step.sampled(s, w, ns, mode)
+            opt.step()
+            opt.zero_grad()
+            if it == 6:
+                with torch.no_grad():
+                    probes.append(m(t[:8].contiguous()).clone())  # general path: flushes what is pending first
+        opt.flush()
+        return [m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone()] + probes + \
+            ([m.modulus.detach().clone()] if name == "pRotatE" else []), opt
+
+    for name in ("TransE", "RotatE", "pRotatE"):
+        (a, oa), (b, ob) = run(True, name), run(False, name)
+        assert oa.state[oa.params[0]].get("defer") and not ob.state[ob.params[0]].get("defer")
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=0, atol=2e-6), (name, float((x - y).abs().max()))
+
+
+def test_pipeline_turns_the_deferred_step_on_and_trains_the_same_model():
+    from mkb_amd import compose, datasets, evaluation, losses, models, optim, sampling
+
+    def run(defer):
+        ds = datasets.Fb15k237(batch_size=2048, shuffle=True, seed=42, num_workers=0)
+        db = datasets.DeviceBatches(ds, "cuda", seed=42)
+        torch.manual_seed(42)
+        m = models.TransE(hidden_dim=16, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+        opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, lazy_rows=True, defer_step=defer)
+        ds.valid, ds.test = [], []
+        pipe = compose.Pipeline(epochs=1, eval_every=100, device="cuda")
+        pipe.learn(model=m, dataset=db, sampling=ns, optimizer=opt, loss=losses.Adversarial(alpha=1.0))
+        m.sync_parameters()
+        return m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(), opt, pipe.metric_loss.get()
+
+    e1, r1, o1, l1 = run(None)
+    e0, r0, o0, l0 = run(False)
+    assert o1.defer_step is True and o0.defer_step is False
+    assert abs(l1 - l0) < 1e-4
+    assert torch.allclose(e1, e0, rtol=0, atol=2e-5) and torch.allclose(r1, r0, rtol=0, atol=2e-5)
