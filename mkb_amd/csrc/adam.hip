@@ -134,6 +134,8 @@ struct AdamRowArgs {
     // advance form (catch-up kernel with g != null): a row's first replayed step takes its gradient row; step `step`
     // uses (neg_step, sqrt_bc2) from here (recorded into consts[step] by the launch), n_ids = number of row blocks,
     // the dense rider (dp ...) is stepped by the blocks behind them
+    int32_t n_rows_listed;  // catch-up kernel: rows to visit (n_ids row blocks of rows_per_block rows each)
+    int32_t rows_per_block; // 2 when D % 4 == 0 (half a workgroup x float4 per row), else 1 (all lanes x float2)
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -148,32 +150,72 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
     p = p + (neg_step * m) * __builtin_amdgcn_rcpf(denom);
 }
 
-// replay the zero-gradient steps (from, to] of one row.  The replay is a serial chain per element (2 transcendentals
-// per step) and a row's gap can be hundreds of steps (entities only the random pool ever touches), so the kernel's
-// duration is its longest chain: kCatchThreads lanes x 2 elements keep that chain short (256 lanes x float4, two passes
-// per 2000-float row: 45 us at the headline shape; 1024 x float2: see DESIGN.md section 5).
+// workgroup size of the catch-up / advance kernel (the sampler's filter and draw blocks that ride it are sized by it too)
 #ifndef MKB_CATCH_THREADS
 #define MKB_CATCH_THREADS 1024
 #endif
 constexpr int kCatchThreads = MKB_CATCH_THREADS;
-__device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int64_t k, float (&pp)[2], float (&mm)[2],
-                                            float (&vv)[2], float (&gg)[2]) {
-    const float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
-    gg[0] = gg[1] = 0.f;
-    if (k + 2 <= A.D && (A.D & 1) == 0) {  // (rows are 8-byte aligned when D is even; an odd D ends on a single element)
-        const float2 a = *reinterpret_cast<const float2 *>(p + k), b = *reinterpret_cast<const float2 *>(m + k),
-                     c = *reinterpret_cast<const float2 *>(v + k);
-        pp[0] = a.x; pp[1] = a.y; mm[0] = b.x; mm[1] = b.y; vv[0] = c.x; vv[1] = c.y;
-        if (A.g) {
-            const float2 d = *reinterpret_cast<const float2 *>(A.g + row * A.D + k);
-            gg[0] = d.x; gg[1] = d.y;
-        }
-    } else {
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// adam_one / adam_zero_grad_step on two elements at once (v_pk_* where the scalar code has v_*: the same IEEE operations,
+// element-wise, so the results are the scalar ones bit for bit); inv_bc2 = v_rcp_f32(sqrt_bc2), taken once per step
+__device__ __forceinline__ void adam_pair(f2 &p, f2 g, f2 &m, f2 &v, float w1, float b2, float w2, float neg_step, float inv_bc2,
+                                          float eps) {
+#pragma clang fp contract(off)
+    m = __builtin_elementwise_fma(f2{w1, w1}, g - m, m);
+    v = v * b2;
+    v = v + (w2 * g) * g;
+    const f2 denom = f2{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)} * inv_bc2 + eps;
+    p = p + (neg_step * m) * f2{__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+}
+
+__device__ __forceinline__ void adam_pair_zero_grad(f2 &p, f2 &m, f2 &v, float w1, float b2, float neg_step, float inv_bc2,
+                                                    float eps) {
+#pragma clang fp contract(off)
+    m = __builtin_elementwise_fma(f2{w1, w1}, f2{0.f, 0.f} - m, m);
+    v = v * b2;  // (+ (w2 * 0) * 0 adds +0 to a non-negative number)
+    const f2 denom = f2{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)} * inv_bc2 + eps;
+    p = p + (neg_step * m) * f2{__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+}
+
+// EPL (2 or 4) consecutive elements of one row per lane; VEC: the row is aligned for one EPL-wide access per array
+template <int EPL>
+struct RowChunk {
+    float p[EPL], m[EPL], v[EPL], g[EPL];
+};
+
+template <int EPL>
+__device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int64_t k, RowChunk<EPL> &c) {
+    const float *p = A.p + row * A.D + k, *m = A.m + row * A.D + k, *v = A.v + row * A.D + k;
+    const float *g = A.g ? A.g + row * A.D + k : nullptr;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < EPL; ++e) c.g[e] = 0.f;
+    if (k + EPL <= A.D && (A.D % EPL) == 0) {
+        if constexpr (EPL == 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(m),
+                         d = *reinterpret_cast<const float4 *>(v);
+            c.p[0] = a.x; c.p[1] = a.y; c.p[2] = a.z; c.p[3] = a.w;
+            c.m[0] = b.x; c.m[1] = b.y; c.m[2] = b.z; c.m[3] = b.w;
+            c.v[0] = d.x; c.v[1] = d.y; c.v[2] = d.z; c.v[3] = d.w;
+            if (g) {
+                const float4 h = *reinterpret_cast<const float4 *>(g);
+                c.g[0] = h.x; c.g[1] = h.y; c.g[2] = h.z; c.g[3] = h.w;
+            }
+        } else {
+            const float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(m),
+                         d = *reinterpret_cast<const float2 *>(v);
+            c.p[0] = a.x; c.p[1] = a.y; c.m[0] = b.x; c.m[1] = b.y; c.v[0] = d.x; c.v[1] = d.y;
+            if (g) {
+                const float2 h = *reinterpret_cast<const float2 *>(g);
+                c.g[0] = h.x; c.g[1] = h.y;
+            }
+        }
+    } else {  // (an odd D ends on a single element)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
             const bool ok = k + e < A.D;
-            pp[e] = ok ? p[k + e] : 0.f; mm[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
-            if (A.g && ok) gg[e] = A.g[row * A.D + k + e];
+            c.p[e] = ok ? p[e] : 0.f; c.m[e] = ok ? m[e] : 0.f; c.v[e] = ok ? v[e] : 0.f;
+            if (g && ok) c.g[e] = g[e];
         }
     }
 }
@@ -183,39 +225,80 @@ __device__ __forceinline__ float2 replay_consts(const AdamRowArgs &A, int s) {
     return (A.g && s == A.step) ? make_float2(A.neg_step, A.sqrt_bc2) : A.consts[s];
 }
 
-__device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, float (&pp)[2],
-                                              float (&mm)[2], float (&vv)[2], float (&gg)[2]) {
-    float *p = A.p + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
-    int s = from + 1;
-    if (A.g) {  // the row's first pending step is the one its gradient row belongs to
-        const float2 c = replay_consts(A, s);
+// replay the steps (from, to] of one chunk: the first with the row's gradient in the advance form, the rest with a zero
+// gradient.  A serial chain per element (2 transcendentals per step); a row's gap can be hundreds of steps (entities only
+// the random pool ever touches), so the chain is kept short: half a workgroup (512 lanes x float4) or a whole one
+// (1024 lanes x float2) per row.
+template <int EPL>
+__device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, RowChunk<EPL> &c) {
+    f2 p[EPL / 2], m[EPL / 2], v[EPL / 2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) adam_one(pp[e], gg[e], mm[e], vv[e], A.w1, A.b2, A.w2, c.x, c.y, A.eps);
+    for (int e = 0; e < EPL / 2; ++e) {
+        p[e] = f2{c.p[2 * e], c.p[2 * e + 1]}; m[e] = f2{c.m[2 * e], c.m[2 * e + 1]}; v[e] = f2{c.v[2 * e], c.v[2 * e + 1]};
+    }
+    int s = from + 1;
+    bool clear = false;
+    if (A.g) {  // the row's first pending step is the one its gradient row belongs to
+        const float2 cs = replay_consts(A, s);
+        const float inv = __builtin_amdgcn_rcpf(cs.y);
+#pragma unroll
+        for (int e = 0; e < EPL / 2; ++e) {
+            const f2 g = f2{c.g[2 * e], c.g[2 * e + 1]};
+            clear |= g.x != 0.f || g.y != 0.f;
+            adam_pair(p[e], g, m[e], v[e], A.w1, A.b2, A.w2, cs.x, inv, A.eps);
+        }
         ++s;
     }
     for (; s <= to; ++s) {
-        const float2 c = replay_consts(A, s);
+        const float2 cs = replay_consts(A, s);
+        const float inv = __builtin_amdgcn_rcpf(cs.y);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) adam_zero_grad_step(pp[e], mm[e], vv[e], A.w1, A.b2, c.x, c.y, A.eps);
+        for (int e = 0; e < EPL / 2; ++e) adam_pair_zero_grad(p[e], m[e], v[e], A.w1, A.b2, cs.x, inv, A.eps);
     }
-    const bool clear = A.g && (gg[0] != 0.f || gg[1] != 0.f);
-    if (k + 2 <= A.D && (A.D & 1) == 0) {
-        *reinterpret_cast<float2 *>(p + k) = make_float2(pp[0], pp[1]);
-        *reinterpret_cast<float2 *>(m + k) = make_float2(mm[0], mm[1]);
-        *reinterpret_cast<float2 *>(v + k) = make_float2(vv[0], vv[1]);
-        if (clear) *reinterpret_cast<float2 *>(A.g + row * A.D + k) = make_float2(0.f, 0.f);
+    float *pp = A.p + row * A.D + k, *mm = A.m + row * A.D + k, *vv = A.v + row * A.D + k;
+    float *gg = A.g ? A.g + row * A.D + k : nullptr;
+    if (k + EPL <= A.D && (A.D % EPL) == 0) {
+        if constexpr (EPL == 4) {
+            *reinterpret_cast<float4 *>(pp) = make_float4(p[0].x, p[0].y, p[1].x, p[1].y);
+            *reinterpret_cast<float4 *>(mm) = make_float4(m[0].x, m[0].y, m[1].x, m[1].y);
+            *reinterpret_cast<float4 *>(vv) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+            if (clear) *reinterpret_cast<float4 *>(gg) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            *reinterpret_cast<float2 *>(pp) = make_float2(p[0].x, p[0].y);
+            *reinterpret_cast<float2 *>(mm) = make_float2(m[0].x, m[0].y);
+            *reinterpret_cast<float2 *>(vv) = make_float2(v[0].x, v[0].y);
+            if (clear) *reinterpret_cast<float2 *>(gg) = make_float2(0.f, 0.f);
+        }
     } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < EPL; ++e)
             if (k + e < A.D) {
-                p[k + e] = pp[e]; m[k + e] = mm[e]; v[k + e] = vv[e];
-                if (clear) A.g[row * A.D + k + e] = 0.f;
+                pp[e] = p[e / 2][e % 2]; mm[e] = m[e / 2][e % 2]; vv[e] = v[e / 2][e % 2];
+                if (clear) gg[e] = 0.f;
             }
     }
 }
 
+// one row: LANES lanes x EPL elements per pass.  The first chunk is requested BEFORE the ownership exchange returns (a
+// global atomic round trip ahead of the row's HBM latency otherwise); lanes that turn out to have nothing to do drop it.
+template <int EPL>
+__device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t row, bool valid, int lane, int lanes, int *s_old,
+                                                 bool ahead) {
+    if (lane == 0 && valid) *s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
+    const int64_t k0 = (int64_t)lane * EPL;
+    RowChunk<EPL> c;
+    if (valid && ahead && k0 < A.D) replay_load<EPL>(A, row, k0, c);
+    __syncthreads();
+    if (!valid) return;
+    const int old = *s_old;
+    if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
+    for (int64_t k = k0; k < A.D; k += (int64_t)EPL * lanes) {
+        if (!ahead || k != k0) replay_load<EPL>(A, row, k, c);
+        replay_finish<EPL>(A, row, k, old, A.step, c);
+    }
+}
+
 __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
-    __shared__ int s_old;
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_draw[];  // only sized when a draw block rides
     if (A.g && A.step > 0 && blockIdx.x == 0 && threadIdx.x == 0)
         A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);  // advance form: the launch after a deferred step records it
@@ -234,26 +317,22 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
                          A.b2, A.w2, A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
         return;
     }
-    int64_t row;
-    if (A.ids) row = A.ids[bid];
-    else if (A.seg_pool) row = bid < A.seg_P ? A.seg_pool[bid]
-                             : (bid < A.seg_P + A.seg_B ? A.seg_sample[3 * (bid - A.seg_P)]
-                                                        : A.seg_sample[3 * (bid - A.seg_P - A.seg_B) + 2]);
-    else row = bid;
-    if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
-    // the row's first elements are requested BEFORE the exchange returns (a global atomic round trip ahead of the row's
-    // HBM latency otherwise); workgroups that turn out to have nothing to do drop them
-    const int64_t k0 = (int64_t)threadIdx.x * 2;
-    float pp[2], mm[2], vv[2], gg[2];
+    __shared__ int s_old2[2];
     const bool ahead = A.ids || A.seg_pool;  // (a flush walks every row, most of them with nothing pending: no guessing there)
-    if (ahead && k0 < A.D) replay_load(A, row, k0, pp, mm, vv, gg);
-    __syncthreads();
-    const int old = s_old;
-    if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
-    for (int64_t k = k0; k < A.D; k += 2 * kCatchThreads) {
-        if (!ahead || k != k0) replay_load(A, row, k, pp, mm, vv, gg);
-        replay_finish(A, row, k, old, A.step, pp, mm, vv, gg);
+    const int rpb = A.rows_per_block, lanes = kCatchThreads / rpb;
+    const int sub = rpb == 2 ? (int)threadIdx.x / lanes : 0, lane = (int)threadIdx.x - sub * lanes;
+    const int64_t r = bid * rpb + sub;
+    const bool valid = r < A.n_rows_listed;
+    int64_t row = 0;
+    if (valid) {
+        if (A.ids) row = A.ids[r];
+        else if (A.seg_pool) row = r < A.seg_P ? A.seg_pool[r]
+                                 : (r < A.seg_P + A.seg_B ? A.seg_sample[3 * (r - A.seg_P)]
+                                                          : A.seg_sample[3 * (r - A.seg_P - A.seg_B) + 2]);
+        else row = r;
     }
+    if (rpb == 2) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
+    else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[0], ahead);
 }
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
@@ -317,6 +396,13 @@ static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float 
 
 namespace mkb {
 
+static void set_row_blocks(AdamRowArgs &A, int64_t rows) {
+    const bool vec4 = (A.D & 3) == 0 && (((uintptr_t)A.p | (uintptr_t)A.m | (uintptr_t)A.v | (uintptr_t)A.g) & 15) == 0;
+    A.rows_per_block = vec4 ? 2 : 1;
+    A.n_rows_listed = (int32_t)rows;
+    A.n_ids = (int32_t)((rows + A.rows_per_block - 1) / A.rows_per_block);
+}
+
 // dense rider of an advance launch -> number of extra workgroups (0 = none)
 static int attach_rider(AdamRowArgs &A, const mkb_adam_dense_t *rider, float lr, float beta1, float beta2, int threads,
                         int64_t *extra) {
@@ -341,7 +427,8 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
     int64_t n = ids ? n_ids : n_rows;
     if (n <= 0 || step_upto <= 0) n = 0;  // nothing can be pending before the first step
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
-    A.n_ids = (int32_t)n;
+    set_row_blocks(A, n);
+    n = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
     if (n + extra == 0) return MKB_OK;
@@ -370,8 +457,8 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
     A.first_row_block = 1;
     A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
     A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
-    const int64_t rows = step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0;  // nothing is pending before the first step
-    A.n_ids = (int32_t)rows;
+    set_row_blocks(A, step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0);  // nothing is pending before the first step
+    const int64_t rows = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
     static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)
