@@ -69,11 +69,26 @@ __host__ __device__ inline int64_t seed_index(const SeedLayout &L, int64_t i, in
     return (((((i >> 3) << L.log2_blocks) + pb) << L.log2_halves) + h) * 512 + l * 8 + (i & 7);
 }
 
+// The tail of a split-K GEMM that its caller folds into the NEXT launch instead of launching it (gemm_mfma.h):
+//   kind 1: out[i] = c0 + c1 * sum_z part[z * n + i]                       (fixed order; consumed by the loss rows)
+//   kind 2: out[c_idx[m]][col] += sum_z part[(z * M + m) * N + col]        (one atomic per element; rides the row backward)
+struct GemmTail {
+    int kind;  // 0: nothing pending
+    const float *part;
+    float *out;
+    const int64_t *c_idx;
+    int M, N, nz;
+    int64_t ldc, n;
+    float c0, c1;
+};
+
 // loss.hip: Adversarial forward + gradient seeds.  defer_finish: the caller sums scratch[1 .. B] itself with
-// adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).
+// adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).  neg_tail (kind 1): the
+// scores are still split-K partials; the rows reduce them while they load them and write the final scores to neg_tail->out.
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
-                       hipStream_t st, bool defer_finish, SeedLayout seeds = SeedLayout{-1, 0});
+                       hipStream_t st, bool defer_finish, SeedLayout seeds = SeedLayout{-1, 0},
+                       const GemmTail *neg_tail = nullptr);
 
 #ifdef __HIPCC__
 // loss = -sum_i rowpart[i] / (2 W) by ONE 256-lane workgroup, fixed order (strided partial sums, wave64 butterfly, then

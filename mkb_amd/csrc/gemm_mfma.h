@@ -292,9 +292,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 
 // out[c_idx[m]][n] += sum_z part[z][m][n]: the scattered product goes through split-K partials and ONE atomic per element
 // (pool ids may repeat and the positive triples' rows share gradient rows) instead of one atomic per element and K split.
-__global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__restrict__ part, float *__restrict__ out,
-                                                             const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz) {
-    const int m = blockIdx.x;
+__device__ __forceinline__ void splitk_scatter_block(const float *__restrict__ part, float *__restrict__ out,
+                                                     const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz, int m) {
     float *row = out + c_idx[m] * ldc;
     for (int n = threadIdx.x * 4; n < N; n += 1024) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -309,11 +308,19 @@ __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__rest
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                                             const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz) {
+    splitk_scatter_block(part, out, c_idx, M, N, ldc, nz, (int)blockIdx.x);
+}
+
 // These products are small (1-2 GFLOP) and short in one dimension: fill the chip by halving the tile height and / or
 // splitting K (ksplit > 1: STORE epilogues go through `partials` [ksplit, M, ldc] and a fixed-order reduction;
 // the atomic epilogue just accumulates).
+// tail: non-null = the caller folds a split-K reduction / scatter into its next launch (GemmTail, common.h): it is described
+// there instead of being launched (kind 0 when the product needed none).
 template <bool A_MK, bool B_NK, int EPI>
-static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr) {
+static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr) {
+    if (tail) tail->kind = 0;
     {   // 128 x 128 / 128 x 64 tiles (4 / 2 accumulators per wave) when the operands allow 16-byte loads
         static const bool off = getenv("MKB_GEMM_NO128") != nullptr;  // A/B switch
         const bool al = (((uintptr_t)G.A | (uintptr_t)G.B) & 15) == 0 && G.lda % 4 == 0 && G.ldb % 4 == 0 && G.M % 4 == 0 &&
@@ -335,8 +342,9 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr) {
                 P2.C = partials; P2.ldc = G.N;
                 if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 64>), grid, dim3(256), lds, st, P2);
                 else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 128>), grid, dim3(256), lds, st, P2);
-                hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M, G.N,
-                                   G.ldc, ks);
+                if (tail) *tail = GemmTail{2, partials, final_c, G.c_idx, G.M, G.N, ks, G.ldc, 0, 0.f, 1.f};
+                else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M,
+                                        G.N, G.ldc, ks);
                 MKB_LAUNCH_CHECK();
                 return MKB_OK;
             }
@@ -346,7 +354,8 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr) {
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
+                if (tail) *tail = GemmTail{1, partials, final_c, nullptr, G.M, G.N, ks, G.ldc, n, c0, c1};
+                else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
             }
             MKB_LAUNCH_CHECK();
             return MKB_OK;

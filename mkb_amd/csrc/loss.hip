@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
                                                                int B, int K, float alpha, const float *__restrict__ scal,
                                                                float *__restrict__ scal_out, float *__restrict__ dpos,
-                                                               float *__restrict__ dneg, float *__restrict__ rowpart, SeedLayout SL) {
+                                                               float *__restrict__ dneg, float *__restrict__ rowpart, SeedLayout SL,
+                                                               GemmTail NT) {
     __shared__ float red[4];
     // scal == nullptr: W is reduced here, by every workgroup alike; workgroup 0 publishes it for the finish step
     const float W = scal ? scal[0] : weight_sum_block(w, B, red);
@@ -74,7 +75,15 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
             const int j = lane + 64 * t;
             const bool ok = j < K;
             c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
-            v[t] = ok ? nrow[j] : 0.f;
+            if (NT.kind == 1) {  // scores still in split-K partials: reduce them here (same order as splitk_reduce_kernel)
+                float acc = 0.f;
+                if (ok)
+                    for (int z = 0; z < NT.nz; ++z) acc += NT.part[(int64_t)z * NT.n + (int64_t)i * K + j];
+                v[t] = ok ? NT.c0 + NT.c1 * acc : 0.f;
+                if (ok) NT.out[(int64_t)i * K + j] = v[t];
+            } else {
+                v[t] = ok ? nrow[j] : 0.f;
+            }
         }
     }
     float m = -INFINITY;
@@ -147,8 +156,13 @@ __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__
 
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
-                       hipStream_t st, bool defer_finish, SeedLayout seeds) {
+                       hipStream_t st, bool defer_finish, SeedLayout seeds, const GemmTail *neg_tail) {
     float *scal = scratch, *rowpart = scratch + 1;
+    GemmTail nt{};
+    if (neg_tail && neg_tail->kind == 1) {
+        if (K > 64 * kRowRegs) return set_error(MKB_ERR_INVALID, "split-K scores can only ride rows of <= %d columns", 64 * kRowRegs);
+        nt = *neg_tail;
+    }
     const float *scal_in = weight_sum;  // W of the whole (sharded) batch when the caller supplies it
     ProfScope ps(MKB_PROF_LOSS, st);
     if (!weight_sum && B > 8192) {      // too many rows for every workgroup to re-reduce W: one extra launch
@@ -156,7 +170,7 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
         scal_in = scal;
     }
     hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds);
+                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt);
     if (!defer_finish)
         hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B,
                            weight_sum ? weight_sum : scal, loss);

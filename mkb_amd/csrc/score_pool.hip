@@ -95,6 +95,8 @@ struct RowStepArgs {
     float *loss_out;
     // ... and extra workgroups behind the B row workgroups reduce the dx partials of the single-pass backward (blocks > 0)
     DxReduce dx;
+    // ... or (MFMA path) add the split-K partials of the scattered product into the table gradient (kind 2: sc.M workgroups)
+    GemmTail sc;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -146,7 +148,12 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
         pool_dx_reduce_block(A.dx, (int)blockIdx.x);
         return;
     }
-    const int64_t i = (int64_t)blockIdx.x - A.dx.blocks;
+    const int sc_blocks = A.sc.kind == 2 ? A.sc.M : 0;
+    if ((int)blockIdx.x < A.dx.blocks + sc_blocks) {
+        splitk_scatter_block(A.sc.part, A.sc.out, A.sc.c_idx, A.sc.M, A.sc.N, A.sc.ldc, A.sc.nz, (int)blockIdx.x - A.dx.blocks);
+        return;
+    }
+    const int64_t i = (int64_t)blockIdx.x - A.dx.blocks - sc_blocks;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *g_h = A.g_ent + h * A.De, *g_r = A.g_rel + r * A.Dr, *g_t = A.g_ent + t * A.De;
@@ -399,7 +406,8 @@ static int run_row_fwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
 
 template <int MODEL, bool HEAD>
 static int run_row_bwd(const RowStepArgs &ra, int64_t B, hipStream_t st) {
-    hipLaunchKernelGGL((row_bwd_kernel<MODEL, HEAD>), dim3((unsigned)(B + ra.dx.blocks)), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL((row_bwd_kernel<MODEL, HEAD>), dim3((unsigned)(B + ra.dx.blocks + (ra.sc.kind == 2 ? ra.sc.M : 0))), dim3(256),
+                       0, st, ra);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -430,7 +438,8 @@ static int dispatch_row_bwd(const mkb_tables_t *tb, bool head, const RowStepArgs
 
 static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
                       int64_t B, int64_t P, float *S, const Workspace &w, const PoolLaunch &L, hipStream_t st,
-                      bool build_queries = true) {
+                      bool build_queries = true, GemmTail *s_tail = nullptr) {
+    if (s_tail) s_tail->kind = 0;
     if (build_queries) {
         RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B,
                    1, tb->phase_div};
@@ -441,7 +450,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
         g.A = w.Q; g.lda = tb->entity_dim; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
         g.C = S; g.ldc = P; g.M = (int)B; g.N = (int)P; g.K = (int)tb->entity_dim; g.c0 = 0.f; g.c1 = 1.f;
         ProfScope ps(MKB_PROF_POOL_FWD, st);
-        return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part);
+        return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part, s_tail);
     }
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);  // (the kernel also zero-fills the entries no row uses)
     A.S = S;
@@ -451,7 +460,8 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
 
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
                       const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
-                      bool chain_queries = true, DxReduce *dx_out = nullptr) {
+                      bool chain_queries = true, DxReduce *dx_out = nullptr, GemmTail *x_tail = nullptr) {
+    if (x_tail) x_tail->kind = 0;
     if (use_mfma(tb)) {
         {   // dQ [B, De] = G [B, P] . ent[pool]
             GemmArgs g{};
@@ -465,7 +475,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             g.A = w.G; g.lda = P; g.B = w.Q; g.ldb = tb->entity_dim; g.b_idx = nullptr;
             g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
-            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part)) return rc;
+            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part, x_tail)) return rc;
         }
     } else {
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
@@ -557,9 +567,9 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
 // The two halves of mkb_pool_step.  Between them the caller may combine the scores of several devices that each
 // hold a slice of the embedding DIMENSIONS (mkb_amd.parallel.DimSharded*): scores are sums over dims, so the halves'
 // only coupling is pos_score / pool_score.
-extern "C" int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
-                                 int64_t B, int64_t K, int mode, float *pos_score, float *pool_score, void *ws,
-                                 void *stream) {
+// s_tail (mkb_pool_step only): the MFMA forward may leave the scores as split-K partials for the loss rows to reduce
+static int pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt, int64_t B,
+                         int64_t K, int mode, float *pos_score, float *pool_score, void *ws, void *stream, GemmTail *s_tail) {
     PoolLaunch L;
     if (int rc = check_pool_call(tb, sample, pool, cnt, B, K, mode, ws, L)) return rc;
     MKB_REQUIRE(pos_score && pool_score, "null pointer");
@@ -575,13 +585,15 @@ extern "C" int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, 
         if (int rc = dispatch_row_fwd(tb, head, ra, B, st)) return rc;
     }
     // negative pass over the shared pool (pipeline.py:230-232)
-    return pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false);
+    return pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false,
+                      (s_tail && P <= 64 * 16) ? s_tail : nullptr);
 }
 
-extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
-                                 const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
-                                 const float *weight_sum, const float *pos_score, const float *pool_score, float *loss,
-                                 void *ws, void *stream) {
+// s_tail: scores still in split-K partials (from pool_step_fwd); fold: the scattered product's tail rides the row backward
+static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                         const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                         const float *weight_sum, const float *pos_score, float *pool_score, float *loss, void *ws,
+                         void *stream, const GemmTail *s_tail) {
     PoolLaunch L;
     if (int rc = check_pool_call(tb, sample, pool, cnt, B, K, mode, ws, L)) return rc;
     MKB_REQUIRE(gr && gr->g_ent && gr->g_rel && weight && pos_score && pool_score && loss, "null pointer");
@@ -594,21 +606,41 @@ extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, 
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
-                                    /*defer_finish=*/true, seed_layout(L))) return rc;
+                                    /*defer_finish=*/true, seed_layout(L), s_tail)) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;
     // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
-    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr)) return rc;
+    static const bool no_fold = getenv("MKB_GEMM_NO_FOLD") != nullptr;
+    if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr,
+                            no_fold ? nullptr : &ra.sc)) return rc;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     return dispatch_row_bwd(tb, head, ra, B, st);
+}
+
+extern "C" int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
+                                 int64_t B, int64_t K, int mode, float *pos_score, float *pool_score, void *ws,
+                                 void *stream) {
+    return pool_step_fwd(tb, sample, pool, cnt, B, K, mode, pos_score, pool_score, ws, stream, nullptr);
+}
+
+extern "C" int mkb_pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
+                                 const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
+                                 const float *weight_sum, const float *pos_score, const float *pool_score, float *loss,
+                                 void *ws, void *stream) {
+    return pool_step_bwd(tb, gr, sample, weight, pool, cnt, B, K, mode, alpha, weight_sum, pos_score,
+                         const_cast<float *>(pool_score), loss, ws, stream, nullptr);
 }
 
 extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const float *weight,
                              const int64_t *pool, const uint16_t *cnt, int64_t B, int64_t K, int mode, float alpha,
                              const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws,
                              void *stream) {
-    if (int rc = mkb_pool_step_fwd(tb, sample, pool, cnt, B, K, mode, pos_score, pool_score, ws, stream)) return rc;
-    return mkb_pool_step_bwd(tb, gr, sample, weight, pool, cnt, B, K, mode, alpha, weight_sum, pos_score, pool_score, loss, ws,
-                             stream);
+    // one call: the split-K tails of the MFMA products fold into the launches that follow them (MKB_GEMM_NO_FOLD=1: A/B)
+    static const bool no_fold = getenv("MKB_GEMM_NO_FOLD") != nullptr;
+    GemmTail s_tail{};
+    if (int rc = pool_step_fwd(tb, sample, pool, cnt, B, K, mode, pos_score, pool_score, ws, stream, no_fold ? nullptr : &s_tail))
+        return rc;
+    return pool_step_bwd(tb, gr, sample, weight, pool, cnt, B, K, mode, alpha, weight_sum, pos_score, pool_score, loss, ws,
+                         stream, s_tail.kind == 1 ? &s_tail : nullptr);
 }
