@@ -144,6 +144,8 @@ class Pipeline:
         else:
             print("\n Epoch: %d. \n" % epoch)
             self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
+        if hasattr(model, "sync_parameters"):
+            model.sync_parameters()  # a row-lazy / deferring optimizer leaves nothing pending behind learn()
         return self
 
     @classmethod
