@@ -97,6 +97,11 @@ struct RowStepArgs {
     DxReduce dx;
     // ... or (MFMA path) add the split-K partials of the scattered product into the table gradient (kind 2: sc.M workgroups)
     GemmTail sc;
+    // few relations (WN18RR: 11, YAGO3-10: 37): ~B / R rows of a batch add into the SAME gradient row, and same-line atomics
+    // serialise in L2.  Row i then adds into copy (i % rel_copies) of a [copies, R, Dr] scratch that the loss kernel zeroed;
+    // rel_fold_kernel adds the copies into g_rel behind the row backward.  rel_copies <= 1: straight into g_rel.
+    float *rel_rep;
+    int rel_copies, n_rel;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     const int64_t i = (int64_t)blockIdx.x - A.dx.blocks - sc_blocks;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
-    float *g_h = A.g_ent + h * A.De, *g_r = A.g_rel + r * A.Dr, *g_t = A.g_ent + t * A.De;
+    float *g_h = A.g_ent + h * A.De, *g_t = A.g_ent + t * A.De;
+    float *g_r = A.rel_copies > 1 ? A.rel_rep + ((int64_t)(i % A.rel_copies) * A.n_rel + r) * A.Dr : A.g_rel + r * A.Dr;
     const float *dq = A.dQ + i * A.De;
     const int64_t sstride = (int64_t)A.B * A.De;
     const float gp = A.dpos[i];
@@ -218,6 +224,15 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
         adversarial_finish_block(A.loss_rowpart, A.B, A.loss_scal, A.loss_out, red);
 }
 
+// g_rel[e] += sum_c rep[c][e]   (fixed order; rep was zeroed by this step's loss kernel)
+__global__ __launch_bounds__(256) void rel_fold_kernel(const float *__restrict__ rep, float *__restrict__ g_rel, int copies, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < copies; ++c) s += rep[(int64_t)c * n + e];
+    g_rel[e] += s;
+}
+
 __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restrict__ src, const uint16_t *__restrict__ cnt,
                                                           float *__restrict__ dst, int64_t n, int64_t P, SeedLayout SL) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -228,6 +243,7 @@ __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restric
 struct Workspace {
     float *Q, *dQ, *G, *dpos, *scratch, *gemm_part, *dXp;
     unsigned long long *xused;
+    float *rel_rep;
     size_t bytes;
 };
 
@@ -246,6 +262,21 @@ static bool use_mfma(const mkb_tables_t *tb) {
 }
 
 static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch &L) {
+    // relation-gradient copies of the row backward: when a relation averages >= 16 rows of the batch, spread them so that
+    // ~4 rows share a copy, within 1 MB of scratch (WN18RR B = 1024: 11 relations -> 23 copies; FB15k-237: none)
+    L.rel_elems = tb->n_relation * tb->relation_dim;
+    L.rel_copies = 1;
+    {
+        static const bool off = getenv("MKB_POOL_NO_REL_COPIES") != nullptr;  // A/B switch
+        const int64_t per_rel = tb->n_relation > 0 ? B / tb->n_relation : 0;
+        if (!off && per_rel >= 16 && L.rel_elems > 0) {
+            int64_t c = per_rel / 4;
+            const int64_t cap = (1 << 18) / L.rel_elems;  // 1 MB of floats
+            if (c > cap) c = cap;
+            if (c > 64) c = 64;
+            if (c >= 2) L.rel_copies = (int)c;
+        }
+    }
     const int NU = units_of(tb);
     const int64_t De = tb->entity_dim, d = tb->hidden_dim;
     const bool cp = tb->model == MKB_ROTATE;
@@ -339,6 +370,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     const size_t nc = (size_t)(L.kpt >= 2 ? 2 : 1) * (L.cplx ? 2 : 1);
     w.dXp = take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * L.pb_halves * 64 * L.dim_slices * 64 * nc * 4 : 0);
     w.xused = (unsigned long long *)take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * 8 * 8 : 0);
+    w.rel_rep = take(L.rel_copies > 1 ? (size_t)L.rel_copies * L.rel_elems * 4 : 0);
     w.bytes = off;
     return w;
 }
@@ -605,8 +637,12 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, nullptr, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
+    if (L.rel_copies > 1) {  // (zeroed by the loss kernel's lanes on their way: no launch, no memset)
+        ra.rel_rep = w.rel_rep; ra.rel_copies = L.rel_copies; ra.n_rel = (int)tb->n_relation;
+    }
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
-                                    /*defer_finish=*/true, seed_layout(L), s_tail)) return rc;
+                                    /*defer_finish=*/true, seed_layout(L), s_tail, ra.rel_rep,
+                                    ra.rel_rep ? (int64_t)L.rel_copies * L.rel_elems : 0)) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;
@@ -615,7 +651,13 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr,
                             no_fold ? nullptr : &ra.sc)) return rc;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
-    return dispatch_row_bwd(tb, head, ra, B, st);
+    if (int rc = dispatch_row_bwd(tb, head, ra, B, st)) return rc;
+    if (ra.rel_rep) {
+        hipLaunchKernelGGL(rel_fold_kernel, dim3((unsigned)((L.rel_elems + 255) / 256)), dim3(256), 0, st, ra.rel_rep, gr->g_rel,
+                           L.rel_copies, L.rel_elems);
+        MKB_LAUNCH_CHECK();
+    }
+    return MKB_OK;
 }
 
 extern "C" int mkb_pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,

@@ -1018,6 +1018,8 @@ struct PoolLaunch {
     int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
     int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the four below
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
+    int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
+    int64_t rel_elems;    // n_relation * relation_dim
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
