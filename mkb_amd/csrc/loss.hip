@@ -57,9 +57,19 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                                                                int B, int K, float alpha, const float *__restrict__ scal,
                                                                float *__restrict__ scal_out, float *__restrict__ dpos,
                                                                float *__restrict__ dneg, float *__restrict__ rowpart, SeedLayout SL,
-                                                               GemmTail NT, float *__restrict__ zero_ptr, int64_t zero_n) {
+                                                               GemmTail NT, float *__restrict__ zero_ptr, int64_t zero_n,
+                                                               int *__restrict__ occ, const int64_t *__restrict__ occ_sample,
+                                                               const int64_t *__restrict__ occ_pool) {
     __shared__ float red[4];
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * 256) zero_ptr[e] = 0.f;
+    if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
+        const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (row < B) {
+            atomicAdd(occ + occ_sample[3 * row], 1);
+            atomicAdd(occ + occ_sample[3 * row + 2], 1);
+            for (int64_t p = row; p < K; p += B) atomicAdd(occ + occ_pool[p], 1);
+        }
+    }
     // scal == nullptr: W is reduced here, by every workgroup alike; workgroup 0 publishes it for the finish step
     const float W = scal ? scal[0] : weight_sum_block(w, B, red);
     if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
                        hipStream_t st, bool defer_finish, SeedLayout seeds, const GemmTail *neg_tail, float *zero_ptr,
-                       int64_t zero_n) {
+                       int64_t zero_n, int *occ, const int64_t *occ_sample, const int64_t *occ_pool) {
     float *scal = scratch, *rowpart = scratch + 1;
     GemmTail nt{};
     if (neg_tail && neg_tail->kind == 1) {
@@ -172,7 +182,8 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
         scal_in = scal;
     }
     hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n);
+                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ, occ_sample,
+                       occ_pool);
     if (!defer_finish)
         hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B,
                            weight_sum ? weight_sum : scal, loss);

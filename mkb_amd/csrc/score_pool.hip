@@ -102,6 +102,14 @@ struct RowStepArgs {
     // rel_fold_kernel adds the copies into g_rel behind the row backward.  rel_copies <= 1: straight into g_rel.
     float *rel_rep;
     int rel_copies, n_rel;
+    // Exclusive rows.  occ[e] = how often entity e occurs among this batch's pool ids, heads and tails: zeroed for exactly
+    // those entries by row_fwd, counted by the loss kernel, read by row_bwd.  An h / t row that occurs once is written by
+    // ONE workgroup of the row backward and by nobody else in that launch (the riders only write pool rows): it takes a
+    // plain read-modify-write instead of one L2 atomic per element (the L2 atomic units retire ~1 element per clock and
+    // channel: row_bwd was bound by them; 72 % of the heads and 57 % of the tails of an FB15k-237 batch occur once).
+    int *occ;
+    const int64_t *pool;
+    int P;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -117,6 +125,10 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
+    if (A.occ && threadIdx.x == 0) {  // (counted by the loss kernel, read by the row backward)
+        A.occ[h] = 0; A.occ[t] = 0;
+        for (int64_t p = i; p < A.P; p += A.B) A.occ[A.pool[p]] = 0;
+    }
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *q = A.Q + i * A.De;
     float acc = 0.f;
@@ -166,6 +178,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     const float *dq = A.dQ + i * A.De;
     const int64_t sstride = (int64_t)A.B * A.De;
     const float gp = A.dpos[i];
+    const bool own_h = A.occ && A.occ[h] == 1, own_t = A.occ && A.occ[t] == 1;  // workgroup-uniform
+    auto add_h = [&](int k, float v) { if (own_h) g_h[k] += v; else atomicAdd(g_h + k, v); };
+    auto add_t = [&](int k, float v) { if (own_t) g_t[k] += v; else atomicAdd(g_t + k, v); };
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
     auto dq_at = [&](int k) {
         float s = 0.f;
@@ -194,8 +209,8 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
             query_bwd_cplx<MODEL, HEAD>(HEAD ? ct : ch, cr, dqn, A.kd, de, dr2);
             if constexpr (HEAD) { dt.re += de.re; dt.im += de.im; } else { dh.re += de.re; dh.im += de.im; }
             dr.re += dr2.re; dr.im += dr2.im;
-            atomicAdd(g_h + u, dh.re); atomicAdd(g_h + A.d + u, dh.im);
-            atomicAdd(g_t + u, dt.re); atomicAdd(g_t + A.d + u, dt.im);
+            add_h(u, dh.re); add_h(A.d + u, dh.im);
+            add_t(u, dt.re); add_t(A.d + u, dt.im);
             atomicAdd(g_r + u, dr.re);
             if constexpr (MODEL == MKB_COMPLEX) atomicAdd(g_r + A.d + u, dr.im);
         }
@@ -211,9 +226,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
             float da, db;
             query_bwd_real<MODEL, HEAD>(HEAD ? vr : vh, HEAD ? vt : vr, dq_at(u), A.kd, da, db);
             if constexpr (HEAD) { dr += da; dt += db; } else { dh += da; dr += db; }
-            atomicAdd(g_h + u, dh);
+            add_h(u, dh);
             atomicAdd(g_r + u, dr);
-            atomicAdd(g_t + u, dt);
+            add_t(u, dt);
         }
     }
     if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z| for the positive pair
@@ -244,6 +259,7 @@ struct Workspace {
     float *Q, *dQ, *G, *dpos, *scratch, *gemm_part, *dXp;
     unsigned long long *xused;
     float *rel_rep;
+    int *occ;
     size_t bytes;
 };
 
@@ -266,6 +282,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // ~4 rows share a copy, within 1 MB of scratch (WN18RR B = 1024: 11 relations -> 23 copies; FB15k-237: none)
     L.rel_elems = tb->n_relation * tb->relation_dim;
     L.rel_copies = 1;
+    L.n_entity = tb->n_entity;
     {
         static const bool off = getenv("MKB_POOL_NO_REL_COPIES") != nullptr;  // A/B switch
         const int64_t per_rel = tb->n_relation > 0 ? B / tb->n_relation : 0;
@@ -371,6 +388,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.dXp = take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * L.pb_halves * 64 * L.dim_slices * 64 * nc * 4 : 0);
     w.xused = (unsigned long long *)take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * 8 * 8 : 0);
     w.rel_rep = take(L.rel_copies > 1 ? (size_t)L.rel_copies * L.rel_elems * 4 : 0);
+    w.occ = (int *)take((size_t)L.n_entity * 4);
     w.bytes = off;
     return w;
 }
@@ -611,6 +629,8 @@ static int pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const in
     const bool head = mode_is_head(mode);
     RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, pos_score, w.dpos, nullptr, nullptr, nullptr,
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
+    static const bool no_own = getenv("MKB_POOL_NO_OWN") != nullptr;  // A/B: every gradient row through atomics
+    if (!no_own) { ra.occ = w.occ; ra.pool = pool; ra.P = (int)P; }
     // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
     {
         ProfScope ps(MKB_PROF_GENERAL_FWD, st);
@@ -637,12 +657,14 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     RowStepArgs ra{tb->ent, tb->rel, tb->modulus, sample, w.Q, w.dQ, nullptr, w.dpos, gr->g_ent, gr->g_rel, gr->g_modulus,
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
+    static const bool no_own = getenv("MKB_POOL_NO_OWN") != nullptr;
+    if (!no_own) { ra.occ = w.occ; ra.pool = pool; ra.P = (int)P; }
     if (L.rel_copies > 1) {  // (zeroed by the loss kernel's lanes on their way: no launch, no memset)
         ra.rel_rep = w.rel_rep; ra.rel_copies = L.rel_copies; ra.n_rel = (int)tb->n_relation;
     }
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
                                     /*defer_finish=*/true, seed_layout(L), s_tail, ra.rel_rep,
-                                    ra.rel_rep ? (int64_t)L.rel_copies * L.rel_elems : 0)) return rc;
+                                    ra.rel_rep ? (int64_t)L.rel_copies * L.rel_elems : 0, ra.occ, sample, pool)) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;

@@ -1020,6 +1020,7 @@ struct PoolLaunch {
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
+    int64_t n_entity;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
