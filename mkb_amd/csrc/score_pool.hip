@@ -672,6 +672,7 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     static const bool no_fold = getenv("MKB_GEMM_NO_FOLD") != nullptr;
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr,
                             no_fold ? nullptr : &ra.sc)) return rc;
+    ra.dx.occ = ra.occ;  // (the dx reduction riding this launch writes pool rows: exclusive ones without atomics)
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     if (int rc = dispatch_row_bwd(tb, head, ra, B, st)) return rc;
     if (ra.rel_rep) {

@@ -957,6 +957,7 @@ struct DxReduce {
     int64_t De;
     int P, d, npb, halves, dim_slices, row_groups, kpt, cplx;
     int blocks;  // npb * halves * 64
+    const int *occ;  // rider of the row backward: occurrence counts of the batch's entities (RowStepArgs::occ), or null
 };
 
 __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int block) {
@@ -969,7 +970,12 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
     for (int rg = 0; rg < R.row_groups; ++rg) any |= ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
     if (!any) return;
     const int nc = R.kpt * (R.cplx ? 2 : 1), NU = R.cplx ? R.d : (int)R.De;
-    float *row = R.g_ent + R.pool[p] * R.De;
+    const int64_t ent = R.pool[p];
+    float *row = R.g_ent + ent * R.De;
+    // an entity that occurs once among the batch's pool ids, heads and tails: nobody else writes its gradient row in this
+    // launch -> plain read-modify-write (workgroup-uniform)
+    const bool own = R.occ && R.occ[ent] == 1;
+    auto add = [&](float *dst, float v) { if (own) *dst += v; else atomicAdd(dst, v); };
     const int per_slot = R.dim_slices * 64 * nc;  // floats of one slot of one row group
     if (nc == 4) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
         for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
@@ -981,8 +987,8 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
                 const float4 v = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
             }
-            atomicAdd(row + u, a.x); atomicAdd(row + u + 1, a.y);
-            atomicAdd(row + R.d + u, a.z); atomicAdd(row + R.d + u + 1, a.w);
+            add(row + u, a.x); add(row + u + 1, a.y);
+            add(row + R.d + u, a.z); add(row + R.d + u + 1, a.w);
         }
         return;
     }
@@ -995,7 +1001,7 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
             if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
             a += R.dXp[(((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + f];
         }
-        atomicAdd(row + (c < R.kpt ? u : R.d + u), a);
+        add(row + (c < R.kpt ? u : R.d + u), a);
     }
 }
 
