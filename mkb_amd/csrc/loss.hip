@@ -80,21 +80,25 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
     const bool in_regs = K <= 64 * kRowRegs;
     float v[kRowRegs], c[kRowRegs];
-    if (in_regs) {
+    if (in_regs && NT.kind != 1) {  // (one straight run of loads: a branch inside this loop serialises their latencies)
 #pragma unroll
         for (int t = 0; t < kRowRegs; ++t) {
             const int j = lane + 64 * t;
             const bool ok = j < K;
             c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
-            if (NT.kind == 1) {  // scores still in split-K partials: reduce them here (same order as splitk_reduce_kernel)
-                float acc = 0.f;
-                if (ok)
-                    for (int z = 0; z < NT.nz; ++z) acc += NT.part[(int64_t)z * NT.n + (int64_t)i * K + j];
-                v[t] = ok ? NT.c0 + NT.c1 * acc : 0.f;
-                if (ok) NT.out[(int64_t)i * K + j] = v[t];
-            } else {
-                v[t] = ok ? nrow[j] : 0.f;
-            }
+            v[t] = ok ? nrow[j] : 0.f;
+        }
+    } else if (in_regs) {  // scores still in split-K partials: reduce them here (same order as splitk_reduce_kernel)
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < K;
+            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
+            float acc = 0.f;
+            if (ok)
+                for (int z = 0; z < NT.nz; ++z) acc += NT.part[(int64_t)z * NT.n + (int64_t)i * K + j];
+            v[t] = ok ? NT.c0 + NT.c1 * acc : 0.f;
+            if (ok) NT.out[(int64_t)i * K + j] = v[t];
         }
     }
     float m = -INFINITY;

@@ -103,7 +103,8 @@ struct RowStepArgs {
     float *rel_rep;
     int rel_copies, n_rel;
     // Exclusive rows.  occ[e] = how often entity e occurs among this batch's pool ids, heads and tails: zeroed for exactly
-    // those entries by row_fwd, counted by the loss kernel, read by row_bwd.  An h / t row that occurs once is written by
+    // those entries by row_fwd, counted by the pooled forward (MFMA path: by the loss kernel), read by row_bwd.  An h / t
+    // row that occurs once is written by
     // ONE workgroup of the row backward and by nobody else in that launch (the riders only write pool rows): it takes a
     // plain read-modify-write instead of one L2 atomic per element (the L2 atomic units retire ~1 element per clock and
     // channel: row_bwd was bound by them; 72 % of the heads and 57 % of the tails of an FB15k-237 batch occur once).
@@ -125,10 +126,12 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
-    if (A.occ && threadIdx.x == 0) {  // (counted by the loss kernel, read by the row backward)
+    if (A.occ && threadIdx.x == 0) {  // (counted by the pooled forward / the loss kernel, read by the row backward)
         A.occ[h] = 0; A.occ[t] = 0;
         for (int64_t p = i; p < A.P; p += A.B) A.occ[A.pool[p]] = 0;
     }
+    if (A.rel_copies > 1)  // the row backward's relation-gradient copies start from zero
+        for (int64_t e = i * 256 + threadIdx.x; e < (int64_t)A.rel_copies * A.n_rel * A.Dr; e += (int64_t)A.B * 256) A.rel_rep[e] = 0.f;
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *q = A.Q + i * A.De;
     float acc = 0.f;
@@ -488,8 +491,9 @@ static int dispatch_row_bwd(const mkb_tables_t *tb, bool head, const RowStepArgs
 
 static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,
                       int64_t B, int64_t P, float *S, const Workspace &w, const PoolLaunch &L, hipStream_t st,
-                      bool build_queries = true, GemmTail *s_tail = nullptr) {
+                      bool build_queries = true, GemmTail *s_tail = nullptr, int *occ = nullptr, bool *occ_counted = nullptr) {
     if (s_tail) s_tail->kind = 0;
+    if (occ_counted) *occ_counted = false;
     if (build_queries) {
         RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B,
                    1, tb->phase_div};
@@ -504,6 +508,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
     }
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);  // (the kernel also zero-fills the entries no row uses)
     A.S = S;
+    if (occ) { A.occ = occ; A.occ_sample = sample; if (occ_counted) *occ_counted = true; }
     ProfScope ps(MKB_PROF_POOL_FWD, st);
     return launcher_of(tb->model)(0, head, L, A, st);
 }
@@ -631,6 +636,7 @@ static int pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const in
                    tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, L.q_slices, tb->phase_div, tb->gamma};
     static const bool no_own = getenv("MKB_POOL_NO_OWN") != nullptr;  // A/B: every gradient row through atomics
     if (!no_own) { ra.occ = w.occ; ra.pool = pool; ra.P = (int)P; }
+    if (L.rel_copies > 1) { ra.rel_rep = w.rel_rep; ra.rel_copies = L.rel_copies; ra.n_rel = (int)tb->n_relation; }
     // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
     {
         ProfScope ps(MKB_PROF_GENERAL_FWD, st);
@@ -638,7 +644,7 @@ static int pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const in
     }
     // negative pass over the shared pool (pipeline.py:230-232)
     return pooled_fwd(tb, head, sample, pool, cnt, B, P, pool_score, w, L, st, /*build_queries=*/false,
-                      (s_tail && P <= 64 * 16) ? s_tail : nullptr);
+                      (s_tail && P <= 64 * 16) ? s_tail : nullptr, ra.occ);
 }
 
 // s_tail: scores still in split-K partials (from pool_step_fwd); fold: the scattered product's tail rides the row backward
@@ -659,12 +665,13 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     // Adversarial forward + gradient seeds (pipeline.py:234 and the head of :236)
     static const bool no_own = getenv("MKB_POOL_NO_OWN") != nullptr;
     if (!no_own) { ra.occ = w.occ; ra.pool = pool; ra.P = (int)P; }
-    if (L.rel_copies > 1) {  // (zeroed by the loss kernel's lanes on their way: no launch, no memset)
+    if (L.rel_copies > 1) {  // (zeroed by the row forward kernel of this step)
         ra.rel_rep = w.rel_rep; ra.rel_copies = L.rel_copies; ra.n_rel = (int)tb->n_relation;
     }
+    // (the occurrence counts: the VALU forward kernel counted them; the MFMA path has no such kernel, the loss rows do it)
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
-                                    /*defer_finish=*/true, seed_layout(L), s_tail, ra.rel_rep,
-                                    ra.rel_rep ? (int64_t)L.rel_copies * L.rel_elems : 0, ra.occ, sample, pool)) return rc;
+                                    /*defer_finish=*/true, seed_layout(L), s_tail, nullptr, 0, use_mfma(tb) ? ra.occ : nullptr,
+                                    sample, pool)) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
     ra.loss_out = loss;

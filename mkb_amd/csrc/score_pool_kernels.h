@@ -58,6 +58,8 @@ struct PoolArgs {
     unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
     DxReduce *dx_reduce_out;     // host side: non-null = do not launch the reduction, describe it here instead
     int g_blocked;               // G is in the tile-blocked seed layout of common.h (SeedLayout of this launch's blocks / halves)
+    int *occ;                    // forward inside mkb_pool_step: count the batch's entities (score_pool.hip RowStepArgs::occ)
+    const int64_t *occ_sample;   //   ... heads and tails of sample [B, 3], and the pool ids
     int64_t De;
     float kd, c0, c1;      // score = c0 + c1 * sum
 #ifdef MKB_TRACE_WG
@@ -208,6 +210,15 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
 #pragma unroll
             for (int v = 0; v < KPT; ++v) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
         }
+    }
+
+    // occurrence counts of the batch's entities for the row backward (fire-and-forget atomics of the first position slice)
+    if (A.occ && sl == 0) {
+        if (tid < TI && i0 + tid < A.B) {
+            atomicAdd(A.occ + A.occ_sample[3 * (int64_t)(i0 + tid)], 1);
+            atomicAdd(A.occ + A.occ_sample[3 * (int64_t)(i0 + tid) + 2], 1);
+        }
+        for (int p = blockIdx.x * WG + tid; p < A.P; p += gridDim.x * WG) atomicAdd(A.occ + A.pool[p], 1);
     }
 
     // positions used by at least one row of the tile, compacted into LDS
