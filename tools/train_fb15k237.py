@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dataset", default="Fb15k237")
+    ap.add_argument("--no-defer", action="store_true", help="apply the optimizer step at once (one more launch per step)")
     args = ap.parse_args()
 
     ds = getattr(datasets, args.dataset)(batch_size=args.batch, shuffle=True, seed=42, num_workers=0)
@@ -38,7 +39,8 @@ def main():
                                         gamma=args.gamma).cuda()
     sampler = sampling.NegativeSampling(size=args.size, train_triples=ds.train, entities=ds.entities,
                                         relations=ds.relations, seed=42)
-    opt = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr, lazy_rows=True, draw_ahead=sampler)
+    opt = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.lr, lazy_rows=True, draw_ahead=sampler,
+                     defer_step=not args.no_defer)  # gradients are cleared through opt.zero_grad() only: the step may wait
     step = FusedTrainStep(model, args.alpha)
     ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations,
                                batch_size=1024, device="cuda", num_workers=0)
