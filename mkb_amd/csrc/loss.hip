@@ -70,12 +70,9 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
             for (int64_t p = row; p < K; p += B) atomicAdd(occ + occ_pool[p], 1);
         }
     }
-    // scal == nullptr: W is reduced here, by every workgroup alike; workgroup 0 publishes it for the finish step
-    const float W = scal ? scal[0] : weight_sum_block(w, B, red);
-    if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= B) return;
+    const int i_raw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = min(i_raw, B - 1);  // (rows past the batch load row B-1 and leave after the workgroup-wide W reduction)
     const float *nrow = neg + (int64_t)i * K;
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
     const bool in_regs = K <= 64 * kRowRegs;
@@ -101,6 +98,11 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
             if (ok) NT.out[(int64_t)i * K + j] = v[t];
         }
     }
+    // scal == nullptr: W is reduced here, by every workgroup alike (its loads and barriers run under the row's loads, which
+    // were issued above); workgroup 0 publishes it for the finish step
+    const float W = scal ? scal[0] : weight_sum_block(w, B, red);
+    if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
+    if (i_raw >= B) return;
     float m = -INFINITY;
     if (in_regs) {
 #pragma unroll

@@ -126,12 +126,7 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x;
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
-    if (A.occ && threadIdx.x == 0) {  // (counted by the pooled forward / the loss kernel, read by the row backward)
-        A.occ[h] = 0; A.occ[t] = 0;
-        for (int64_t p = i; p < A.P; p += A.B) A.occ[A.pool[p]] = 0;
-    }
-    if (A.rel_copies > 1)  // the row backward's relation-gradient copies start from zero
-        for (int64_t e = i * 256 + threadIdx.x; e < (int64_t)A.rel_copies * A.n_rel * A.Dr; e += (int64_t)A.B * 256) A.rel_rep[e] = 0.f;
+
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *q = A.Q + i * A.De;
     float acc = 0.f;
@@ -156,6 +151,13 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
     }
     acc = block_sum_256_row(acc, red);
     if (threadIdx.x == 0) A.pos_score[i] = finish_score<MODEL>(acc, A.gamma, MODEL == MKB_PROTATE ? A.modulus[0] : 0.f);
+    // housekeeping for the later kernels of the step, behind the row's own work (fire-and-forget stores)
+    if (A.occ && threadIdx.x == 64) {  // (counted by the pooled forward / the loss kernel, read by the row backward)
+        A.occ[h] = 0; A.occ[t] = 0;
+        for (int64_t p = i; p < A.P; p += A.B) A.occ[A.pool[p]] = 0;
+    }
+    if (A.rel_copies > 1)  // the row backward's relation-gradient copies start from zero
+        for (int64_t e = i * 256 + threadIdx.x; e < (int64_t)A.rel_copies * A.n_rel * A.Dr; e += (int64_t)A.B * 256) A.rel_rep[e] = 0.f;
 }
 
 // backward of the positive pair + chain of both query gradients into the rows of h, r, t
