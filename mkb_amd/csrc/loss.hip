@@ -18,18 +18,20 @@
 
 namespace mkb {
 
+// (the first 256 lanes of the workgroup do the work: the same tree, hence the same bits, for 256- and 512-lane workgroups)
 __device__ __forceinline__ float block_sum_256(float v, float *red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
-    if (lane == 0) red[wave] = v;
+    if (lane == 0 && wave < 4) red[wave] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
 
 __device__ __forceinline__ float weight_sum_block(const float *__restrict__ w, int B, float *red) {
     float acc = 0.f;
-    for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
+    if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
     return block_sum_256(acc, red);
 }
 
@@ -51,8 +53,12 @@ __device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn
 
 // one wave per row; rowpart[i] = w_i * (ps_i + ns_i).  Rows of up to 64 * kRowRegs columns are read ONCE into registers
 // (the three passes -- max, partition sums, gradient seeds -- then run on registers); longer rows re-read global memory.
+// TILE (tile-blocked seed layout only): 512 lanes = the 8 rows of one row tile.  Written straight from the rows, the
+// seeds of one row are 4-byte stores 2 KB apart (512 k partial-line writes per 1024 rows: the kernel's duration grew
+// linearly with the rows, 12 -> 41 us from 1024 to 8192); staged through LDS the tile goes out as whole 2 KB runs.
 constexpr int kRowRegs = 16;
-__global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
+template <bool TILE>
+__global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
                                                                int B, int K, float alpha, const float *__restrict__ scal,
                                                                float *__restrict__ scal_out, float *__restrict__ dpos,
@@ -60,10 +66,17 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                                                                GemmTail NT, float *__restrict__ zero_ptr, int64_t zero_n,
                                                                int *__restrict__ occ, const int64_t *__restrict__ occ_sample,
                                                                const int64_t *__restrict__ occ_pool) {
+    constexpr int NTH = TILE ? 512 : 256, RPB = NTH / 64;  // lanes and rows per workgroup
     __shared__ float red[4];
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * 256) zero_ptr[e] = 0.f;
+    extern __shared__ float s_seed[];  // TILE: [cap positions][9] (8 rows + 1 pad), cap = blocks * halves * 64
+    const int cap = TILE ? (64 << (SL.log2_blocks + SL.log2_halves)) : 0;
+    if constexpr (TILE) {
+        for (int e = threadIdx.x; e < cap * 9; e += NTH) s_seed[e] = 0.f;  // (padding slots and rows past the batch stay 0)
+        __syncthreads();
+    }
+    for (int64_t e = (int64_t)blockIdx.x * NTH + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NTH) zero_ptr[e] = 0.f;
     if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
-        const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6);
         if (row < B) {
             atomicAdd(occ + occ_sample[3 * row], 1);
             atomicAdd(occ + occ_sample[3 * row + 2], 1);
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
         }
     }
     const int lane = threadIdx.x & 63;
-    const int i_raw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i_raw = blockIdx.x * RPB + (threadIdx.x >> 6);
     const int i = min(i_raw, B - 1);  // (rows past the batch load row B-1 and leave after the workgroup-wide W reduction)
     const float *nrow = neg + (int64_t)i * K;
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
@@ -102,7 +115,9 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
     // were issued above); workgroup 0 publishes it for the finish step
     const float W = scal ? scal[0] : weight_sum_block(w, B, red);
     if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
-    if (i_raw >= B) return;
+    const bool live = i_raw < B;
+    if (!TILE && !live) return;
+    if (live) {
     float m = -INFINITY;
     if (in_regs) {
 #pragma unroll
@@ -145,7 +160,11 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
 #pragma unroll
         for (int t = 0; t < kRowRegs; ++t) {
             const int j = lane + 64 * t;
-            if (j < K) dneg[seed_index(SL, i, j, K)] = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
+            if (j < K) {
+                const float g = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
+                if constexpr (TILE) s_seed[j * 9 + (i & 7)] = g;
+                else dneg[seed_index(SL, i, j, K)] = g;
+            }
         }
     } else {
         for (int j = lane; j < K; j += 64) {
@@ -155,13 +174,31 @@ __global__ __launch_bounds__(256) void adversarial_rows_kernel(const float *__re
                 const float vv = nrow[j];
                 g = coef * (cc * fast_exp(alpha * vv - m) * invz) * fast_sigmoid(vv);
             }
-            dneg[seed_index(SL, i, j, K)] = g;
+            if constexpr (TILE) s_seed[j * 9 + (i & 7)] = g;
+            else dneg[seed_index(SL, i, j, K)] = g;
         }
     }
     if (lane == 0) {
         const float p = pos[i];
         dpos[i] = -coef * fast_sigmoid(-p);
         rowpart[i] = wi * (fast_log_sigmoid(p) + s * invz);
+    }
+    }  // live
+    if constexpr (TILE) {
+        // the tile's region of the blocked layout is blocks * halves runs of 512 floats ([64 lanes][8 rows]); run c holds the
+        // slots (l, c % halves) of position block c / halves: position p = pb + blocks * (l * halves + h)
+        __syncthreads();
+        const int blocks = 1 << SL.log2_blocks, halves = 1 << SL.log2_halves;
+        float *tile_out = dneg + (int64_t)blockIdx.x * cap * 8;
+        for (int q = threadIdx.x; q < cap * 2; q += NTH) {  // one float4 (4 rows of one slot) per step
+            const int run = q >> 7, off = (q & 127) * 4, l = off >> 3, r0 = off & 7;
+            const int pb = run >> SL.log2_halves, h = run & (halves - 1);
+            const int p = pb + blocks * (l * halves + h);
+            const float *src = s_seed + p * 9 + r0;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < cap) o = make_float4(src[0], src[1], src[2], src[3]);
+            *reinterpret_cast<float4 *>(tile_out + (int64_t)q * 4) = o;
+        }
     }
 }
 
@@ -187,9 +224,17 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
         hipLaunchKernelGGL(weight_sum_kernel, dim3(1), dim3(256), 0, st, weight, (int)B, scal);
         scal_in = scal;
     }
-    hipLaunchKernelGGL(adversarial_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                       (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ, occ_sample,
-                       occ_pool);
+    if (seeds.log2_blocks >= 0) {  // tile-blocked seeds: one row tile per 512-lane workgroup, staged through LDS
+        const int cap = 64 << (seeds.log2_blocks + seeds.log2_halves);
+        if (cap < K) return set_error(MKB_ERR_INVALID, "blocked seed layout holds %d positions, the rows have %d", cap, (int)K);
+        hipLaunchKernelGGL(adversarial_rows_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(512), (size_t)cap * 9 * 4, st, pos, neg,
+                           weight, cnt, (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ,
+                           occ_sample, occ_pool);
+    } else {
+        hipLaunchKernelGGL(adversarial_rows_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
+                           (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ, occ_sample,
+                           occ_pool);
+    }
     if (!defer_finish)
         hipLaunchKernelGGL(adversarial_finish_kernel, dim3(1), dim3(256), 0, st, rowpart, (int)B,
                            weight_sum ? weight_sum : scal, loss);

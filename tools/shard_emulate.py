@@ -20,7 +20,7 @@ def main(world):
     m = parallel.shard_dims(full, 0, world, "cuda")
     m._dim_shard = (0, 1, m._dim_shard[2], m._dim_shard[3])  # no collective
     ns = sampling.NegativeSampling(size=bench.K, train_triples=train_np, entities=ents, relations=rels, seed=42)
-    opt = optim.Adam([p for p in m.parameters() if p.requires_grad and p is not m.modulus], lr=bench.LR, lazy_rows=True)
+    opt = optim.Adam([p for p in m.parameters() if p.requires_grad and p is not m.modulus], lr=bench.LR, lazy_rows=True, draw_ahead=ns, defer_step=True)
     step = parallel.DimShardedStep(m, bench.ALPHA)
     train = torch.as_tensor(train_np, device="cuda")
     w = subsampling_weights(train_np).cuda()
