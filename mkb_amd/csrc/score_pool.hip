@@ -349,7 +349,11 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
         const char *e = getenv("MKB_POOL_BWD1");  // A/B switch: 0 = the two-pass merged kernel
         L.bwd1 = (!L.mfma && !(e && e[0] == '0')) ? 1 : 0;
         L.row_groups = 0; L.cplx = cp ? 1 : 0; L.pb_halves = 0; L.tiles_per_wave = 1;
-        const int k1 = L.kpt >= 2 ? 2 : 1, nc = k1 * (cp ? 2 : 1);
+        // units per lane of the single-pass backward: 2 (1 for odd rows); real-valued models with long rows take 4 -- the
+        // same 4 floats per lane and position as RotatE's two complex dims, half the per-position bookkeeping of 2
+        static const bool no_k4 = getenv("MKB_POOL_BWD1_NO_K4") != nullptr;  // A/B switch
+        const int k1 = (!cp && even4 && NU >= 512 && !no_k4) ? 4 : (L.kpt >= 2 ? 2 : 1), nc = k1 * (cp ? 2 : 1);
+        L.bkpt = k1;
         const int lanes1 = (NU + k1 - 1) / k1;
         L.dim_slices = (lanes1 + 63) / 64;
         const int max_halves = 128 * 1024 / (64 * nc * 64 * 4);  // 2 at nc = 4, 4 at nc = 2, 8 at nc = 1
@@ -389,7 +393,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.scratch = take((size_t)(B + 1) * 4);
     w.gemm_part = take(L.mfma ? (size_t)8 * B * (P > De ? P : De) * 4 : 0);  // split-K partials of the MFMA path
     // single-pass backward: dx partials per row group [groups][blocks][slots][dim slices][64 lanes][NC] + used-slot masks
-    const size_t nc = (size_t)(L.kpt >= 2 ? 2 : 1) * (L.cplx ? 2 : 1);
+    const size_t nc = (size_t)L.bkpt * (L.cplx ? 2 : 1);
     w.dXp = take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * L.pb_halves * 64 * L.dim_slices * 64 * nc * 4 : 0);
     w.xused = (unsigned long long *)take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * 8 * 8 : 0);
     w.rel_rep = take(L.rel_copies > 1 ? (size_t)L.rel_copies * L.rel_elems * 4 : 0);

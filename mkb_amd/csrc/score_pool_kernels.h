@@ -914,6 +914,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                     if constexpr (NC == 1) upd += dx0[0];
                     else if constexpr (NC == 2 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; }
                     else if constexpr (NC == 2) { upd.x += dx0[0]; upd.y += dx1[0]; }
+                    else if constexpr (NC == 4 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx0[2]; upd.w += dx0[3]; }
                     else { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx1[0]; upd.w += dx1[1]; }
                     *slot = upd;
                 }
@@ -988,7 +989,7 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
     const bool own = R.occ && R.occ[ent] == 1;
     auto add = [&](float *dst, float v) { if (own) *dst += v; else atomicAdd(dst, v); };
     const int per_slot = R.dim_slices * 64 * nc;  // floats of one slot of one row group
-    if (nc == 4) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
+    if (nc == 4 && R.cplx) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
         for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
             const int u = e * 2;
             if (u >= NU) continue;
@@ -1033,7 +1034,8 @@ struct PoolLaunch {
     int fkpt, fnw;        // the same for the forward kernel (it amortises its wave reduction over more units per lane)
     int fwd_slices, q_slices, x_slices;
     int mfma;             // bilinear models: dense fp32 MFMA GEMMs instead of the tile kernels
-    int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the four below
+    int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the five below
+    int bkpt;             // its units per lane (1, 2, or 4 for real-valued models with long rows)
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
@@ -1099,7 +1101,11 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
 
 template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
-    if (which == 4) return L0.kpt >= 2 ? launch_bwd1<MODEL, HEAD, 2>(L0, A, st) : launch_bwd1<MODEL, HEAD, 1>(L0, A, st);
+    if (which == 4) {
+        if constexpr (!ModelTraits<MODEL>::cplx_pair)
+            if (L0.bkpt == 4) return launch_bwd1<MODEL, HEAD, 4>(L0, A, st);
+        return L0.bkpt >= 2 ? launch_bwd1<MODEL, HEAD, 2>(L0, A, st) : launch_bwd1<MODEL, HEAD, 1>(L0, A, st);
+    }
     PoolLaunch L = L0;
     if (which == 0) { L.kpt = L0.fkpt; L.nw = L0.fnw; }
     if (L.kpt == 1 && L.nw == 1) return launch_cfg<MODEL, HEAD, 1, 1>(which, L, A, st);
