@@ -85,12 +85,11 @@ struct GemmTail {
 // loss.hip: Adversarial forward + gradient seeds.  defer_finish: the caller sums scratch[1 .. B] itself with
 // adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).  neg_tail (kind 1): the
 // scores are still split-K partials; the rows reduce them while they load them and write the final scores to neg_tail->out.
-// zero_ptr / zero_n: scratch the launch clears on its way (the relation-gradient copies of the row backward).
 // occ (+ the batch's sample [B, 3] and pool [K columns]): occurrence counts of the batch's entities (RowStepArgs::occ).
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
                        hipStream_t st, bool defer_finish, SeedLayout seeds = SeedLayout{-1, 0},
-                       const GemmTail *neg_tail = nullptr, float *zero_ptr = nullptr, int64_t zero_n = 0, int *occ = nullptr,
+                       const GemmTail *neg_tail = nullptr, int *occ = nullptr,
                        const int64_t *occ_sample = nullptr, const int64_t *occ_pool = nullptr);
 
 #ifdef __HIPCC__

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
                                                                int B, int K, float alpha, const float *__restrict__ scal,
                                                                float *__restrict__ scal_out, float *__restrict__ dpos,
                                                                float *__restrict__ dneg, float *__restrict__ rowpart, SeedLayout SL,
-                                                               GemmTail NT, float *__restrict__ zero_ptr, int64_t zero_n,
+                                                               GemmTail NT,
                                                                int *__restrict__ occ, const int64_t *__restrict__ occ_sample,
                                                                const int64_t *__restrict__ occ_pool) {
     constexpr int NTH = TILE ? 512 : 256, RPB = NTH / 64;  // lanes and rows per workgroup
@@ -74,7 +74,6 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
         for (int e = threadIdx.x; e < cap * 9; e += NTH) s_seed[e] = 0.f;  // (padding slots and rows past the batch stay 0)
         __syncthreads();
     }
-    for (int64_t e = (int64_t)blockIdx.x * NTH + threadIdx.x; e < zero_n; e += (int64_t)gridDim.x * NTH) zero_ptr[e] = 0.f;
     if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
         const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6);
         if (row < B) {
@@ -210,8 +209,8 @@ __global__ __launch_bounds__(256) void adversarial_finish_kernel(const float *__
 
 int adversarial_launch(const float *pos, const float *neg, const float *weight, const uint16_t *cnt, int64_t B, int64_t K,
                        float alpha, const float *weight_sum, float *loss, float *dpos, float *dneg, float *scratch,
-                       hipStream_t st, bool defer_finish, SeedLayout seeds, const GemmTail *neg_tail, float *zero_ptr,
-                       int64_t zero_n, int *occ, const int64_t *occ_sample, const int64_t *occ_pool) {
+                       hipStream_t st, bool defer_finish, SeedLayout seeds, const GemmTail *neg_tail,
+                       int *occ, const int64_t *occ_sample, const int64_t *occ_pool) {
     float *scal = scratch, *rowpart = scratch + 1;
     GemmTail nt{};
     if (neg_tail && neg_tail->kind == 1) {
@@ -228,11 +227,11 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
         const int cap = 64 << (seeds.log2_blocks + seeds.log2_halves);
         if (cap < K) return set_error(MKB_ERR_INVALID, "blocked seed layout holds %d positions, the rows have %d", cap, (int)K);
         hipLaunchKernelGGL(adversarial_rows_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(512), (size_t)cap * 9 * 4, st, pos, neg,
-                           weight, cnt, (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ,
+                           weight, cnt, (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, occ,
                            occ_sample, occ_pool);
     } else {
         hipLaunchKernelGGL(adversarial_rows_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
-                           (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, zero_ptr, zero_n, occ, occ_sample,
+                           (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, occ, occ_sample,
                            occ_pool);
     }
     if (!defer_finish)

@@ -98,7 +98,7 @@ struct RowStepArgs {
     // ... or (MFMA path) add the split-K partials of the scattered product into the table gradient (kind 2: sc.M workgroups)
     GemmTail sc;
     // few relations (WN18RR: 11, YAGO3-10: 37): ~B / R rows of a batch add into the SAME gradient row, and same-line atomics
-    // serialise in L2.  Row i then adds into copy (i % rel_copies) of a [copies, R, Dr] scratch that the loss kernel zeroed;
+    // serialise in L2.  Row i then adds into copy (i % rel_copies) of a [copies, R, Dr] scratch that the row forward zeroed;
     // rel_fold_kernel adds the copies into g_rel behind the row backward.  rel_copies <= 1: straight into g_rel.
     float *rel_rep;
     int rel_copies, n_rel;
@@ -676,7 +676,7 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     }
     // (the occurrence counts: the VALU forward kernel counted them; the MFMA path has no such kernel, the loss rows do it)
     if (int rc = adversarial_launch(pos_score, pool_score, weight, cnt, B, P, alpha, weight_sum, loss, w.dpos, w.G, w.scratch, st,
-                                    /*defer_finish=*/true, seed_layout(L), s_tail, nullptr, 0, use_mfma(tb) ? ra.occ : nullptr,
+                                    /*defer_finish=*/true, seed_layout(L), s_tail, use_mfma(tb) ? ra.occ : nullptr,
                                     sample, pool)) return rc;
     ra.loss_rowpart = w.scratch + 1;
     ra.loss_scal = weight_sum ? weight_sum : w.scratch;
