@@ -6,7 +6,7 @@
 set -u
 R=$(pwd)
 O=$R/gpurun_out/refresh
-rm -rf $O; mkdir -p $O
+rm -rf $O; mkdir -p $O   # (everything below is regenerated)
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --no-cpu-baseline --mrr-epochs 0 --no-variants"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o run -- $BENCH --steps 60 --warmup 10 > $O/bench_under_rocprof.json 2> $O/ktrace.log
@@ -30,5 +30,7 @@ for par in table-rows dims rows; do
   MKB_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 10 --warmup 3 --config yago310-rotate --parallelism $par 2>/dev/null | tail -1 >> $O/one_device_world2.txt
 done
 timeout 300 python tools/general_path_speed.py > $O/general_path.txt 2>&1
+for w in 1 2 4 8; do timeout 300 python tools/shard_emulate.py $w 2>&1 | grep -v amdgpu.ids >> $O/shard_emulate.txt; done
+timeout 300 python tools/pipeline_speed.py 2>&1 | tail -1 > $O/pipeline_speed.txt
 rm -rf $O/ktrace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_clk   # keep the summaries, not the databases
 ls -la $O
