@@ -16,6 +16,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mkb {
@@ -212,17 +214,19 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
             }
         }
     };
-    auto store_tiles = [&](int k0) {
+    // full_c: the whole chunk lies inside the K range (every chunk but possibly the last): no per-element range selects
+    auto store_tiles = [&](int k0, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             int r, kk;
             coord(A_MK, TM, e, r, kk);
             float *d = sA + r * LD + kk;
             if constexpr (A_MK) {  // float4 along k: zero the part beyond the range
-                d[0] = k0 + kk < k_hi ? ra[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? ra[e].y : 0.f;
-                d[2] = k0 + kk + 2 < k_hi ? ra[e].z : 0.f; d[3] = k0 + kk + 3 < k_hi ? ra[e].w : 0.f;
+                d[0] = FULL || k0 + kk < k_hi ? ra[e].x : 0.f; d[1] = FULL || k0 + kk + 1 < k_hi ? ra[e].y : 0.f;
+                d[2] = FULL || k0 + kk + 2 < k_hi ? ra[e].z : 0.f; d[3] = FULL || k0 + kk + 3 < k_hi ? ra[e].w : 0.f;
             } else {
-                const bool ok = k0 + kk < k_hi;
+                const bool ok = FULL || k0 + kk < k_hi;
                 d[0] = ok ? ra[e].x : 0.f; d[LD] = ok ? ra[e].y : 0.f; d[2 * LD] = ok ? ra[e].z : 0.f; d[3 * LD] = ok ? ra[e].w : 0.f;
             }
         }
@@ -232,10 +236,10 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
             coord(B_NK, TN, e, r, kk);
             float *d = sB + r * LD + kk;
             if constexpr (B_NK) {
-                d[0] = k0 + kk < k_hi ? rb[e].x : 0.f; d[1] = k0 + kk + 1 < k_hi ? rb[e].y : 0.f;
-                d[2] = k0 + kk + 2 < k_hi ? rb[e].z : 0.f; d[3] = k0 + kk + 3 < k_hi ? rb[e].w : 0.f;
+                d[0] = FULL || k0 + kk < k_hi ? rb[e].x : 0.f; d[1] = FULL || k0 + kk + 1 < k_hi ? rb[e].y : 0.f;
+                d[2] = FULL || k0 + kk + 2 < k_hi ? rb[e].z : 0.f; d[3] = FULL || k0 + kk + 3 < k_hi ? rb[e].w : 0.f;
             } else {
-                const bool ok = k0 + kk < k_hi;
+                const bool ok = FULL || k0 + kk < k_hi;
                 d[0] = ok ? rb[e].x : 0.f; d[LD] = ok ? rb[e].y : 0.f; d[2 * LD] = ok ? rb[e].z : 0.f; d[3 * LD] = ok ? rb[e].w : 0.f;
             }
         }
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
 
     if (k_lo < k_hi) load_tiles(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
-        store_tiles(k0);
+        if (k0 + KC <= k_hi) store_tiles(k0, std::true_type{});
+        else store_tiles(k0, std::false_type{});
         __syncthreads();
         if (k0 + KC < k_hi) load_tiles(k0 + KC);  // next chunk in flight under this chunk's 64 MFMAs
         const float *pa = sA + (wm + (lane & 31)) * LD + (lane >> 5);
@@ -331,7 +336,8 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             const bool narrow = tiles128 < 200;
             const int tiles = narrow ? ((G.M + 127) / 128) * ((G.N + 63) / 64) : tiles128;
             int ks = 1;
-            while (tiles * ks < 200 && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
+            static const int min_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 200;  // experiment knob
+            while (tiles * ks < min_wg && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
             G.ksplit = ks;
             float *final_c = G.C;
             const int tn = narrow ? 64 : 128;
