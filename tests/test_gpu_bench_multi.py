@@ -12,8 +12,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("parallelism", ["dims", "rows", "table-rows"])
-def test_bench_two_ranks_on_one_device(parallelism):
+@pytest.mark.parametrize("parallelism,scaling", [("dims", "weak"), ("rows", "weak"), ("table-rows", "weak"), ("rows", "strong"),
+                                                 ("table-rows", "strong")])
+def test_bench_two_ranks_on_one_device(parallelism, scaling):
     from conftest import ROOT
 
     with socket.socket() as s:
@@ -22,11 +23,12 @@ def test_bench_two_ranks_on_one_device(parallelism):
     env = dict(os.environ, MKB_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--config", "wn18rr-rotate", "--parallelism", parallelism]
+           "--config", "wn18rr-rotate", "--parallelism", parallelism, "--scaling", scaling]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "triples/s"
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["unit"] == "triples/s" and d["scaling"] == scaling
+    assert d["config"]["global_batch"] == (2048 if scaling == "weak" else 1024)
     want = {"dims": "dims2", "rows": "dp2", "table-rows": "table-rows2"}[parallelism]
     assert d["config"]["parallelism"].startswith(want), d["config"]["parallelism"]
