@@ -135,7 +135,8 @@ struct AdamRowArgs {
     // uses (neg_step, sqrt_bc2) from here (recorded into consts[step] by the launch), n_ids = number of row blocks,
     // the dense rider (dp ...) is stepped by the blocks behind them
     int32_t n_rows_listed;  // catch-up kernel: rows to visit (n_ids row blocks of rows_per_block rows each)
-    int32_t rows_per_block; // 2 when D % 4 == 0 (half a workgroup x float4 per row), else 1 (all lanes x float2)
+    int32_t rows_per_block; // power of two <= 16: kCatchThreads / rows_per_block lanes x (float4 | float2) cover one row
+    int32_t vec4;           // rows are read as float4 per lane (D % 4 == 0, 16-byte aligned arrays), else float2 / scalar
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -317,10 +318,10 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
                          A.b2, A.w2, A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
         return;
     }
-    __shared__ int s_old2[2];
+    __shared__ int s_old2[16];
     const bool ahead = A.ids || A.seg_pool;  // (a flush walks every row, most of them with nothing pending: no guessing there)
     const int rpb = A.rows_per_block, lanes = kCatchThreads / rpb;
-    const int sub = rpb == 2 ? (int)threadIdx.x / lanes : 0, lane = (int)threadIdx.x - sub * lanes;
+    const int sub = (int)threadIdx.x / lanes, lane = (int)threadIdx.x - sub * lanes;
     const int64_t r = bid * rpb + sub;
     const bool valid = r < A.n_rows_listed;
     int64_t row = 0;
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
                                                           : A.seg_sample[3 * (r - A.seg_P - A.seg_B) + 2]);
         else row = r;
     }
-    if (rpb == 2) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
-    else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[0], ahead);
+    if (A.vec4) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
+    else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
 }
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
@@ -398,7 +399,14 @@ namespace mkb {
 
 static void set_row_blocks(AdamRowArgs &A, int64_t rows) {
     const bool vec4 = (A.D & 3) == 0 && (((uintptr_t)A.p | (uintptr_t)A.m | (uintptr_t)A.v | (uintptr_t)A.g) & 15) == 0;
-    A.rows_per_block = vec4 ? 2 : 1;
+    A.vec4 = vec4 ? 1 : 0;
+    // as many rows per 1024-lane workgroup as fit with one chunk per lane (whole waves per row): 2000-float rows 2,
+    // 1000-float rows 4, the 250-float rows of an 8-way dimension shard 8 -- short rows used to idle most of the lanes
+    const int64_t per_lane = vec4 ? 4 : 2;
+    int64_t lanes = ((A.D + per_lane - 1) / per_lane + 63) / 64 * 64;
+    int rpb = 1;
+    while (rpb < 16 && (int64_t)kCatchThreads / (rpb * 2) >= lanes) rpb *= 2;
+    A.rows_per_block = rpb;
     A.n_rows_listed = (int32_t)rows;
     A.n_ids = (int32_t)((rows + A.rows_per_block - 1) / A.rows_per_block);
 }
