@@ -138,7 +138,8 @@ int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *
                   const float *weight_sum, float *pos_score, float *pool_score, float *loss, void *ws, void *stream);
 /* The two halves of mkb_pool_step (mkb_pool_step == fwd then bwd on the same buffers).  A caller that shards the
  * embedding DIMENSIONS over devices sums pos_score / pool_score across devices between the halves (scores are sums
- * over dims) and adds gamma once; each device then back-propagates into its own slice with no further exchange.
+ * over dims; gamma must enter once: e.g. only one device's tables carry it) and each device then back-propagates into its
+ * own slice with no further exchange.
  * The backward half continues the forward half's workspace: besides the queries it holds the per-step occurrence counts
  * of the batch's entities (a gradient row whose entity occurs once is written without atomics) -- same ws, same batch,
  * forward first. */

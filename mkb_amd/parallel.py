@@ -163,8 +163,8 @@ def _dim_slices(model, rank, world):
 
 def shard_dims(model, rank, world, device=None):
     """A model of the same class holding this rank's 1/world of the embedding dims of ``model`` (a full model,
-    e.g. freshly initialised with the reference's seed on the CPU).  Its forward returns PARTIAL scores (gamma is
-    added once after the all-reduce, by DimShardedStep)."""
+    e.g. freshly initialised with the reference's seed on the CPU).  Its forward returns PARTIAL scores (rank 0's include
+    gamma, so that the all-reduced sum holds it once)."""
     import math
 
     ec, rc = _dim_slices(model, rank, world)
@@ -177,8 +177,11 @@ def shard_dims(model, rank, world, device=None):
         if hasattr(model, "modulus"):
             local.modulus.copy_(model.modulus.detach().cpu())
     phase_div = torch.tensor(model.embedding_range.item() / math.pi, dtype=torch.float32).item()
-    local._consts_override = (0.0, phase_div)  # partial scores: gamma is added after the cross-rank sum
-    local._dim_shard = (rank, world, model.gamma.item(), model.name in ("TransE", "RotatE", "pRotatE"))
+    uses_gamma = model.name in ("TransE", "RotatE", "pRotatE")
+    # partial scores: rank 0's carry gamma, the others' do not, so the cross-rank sum holds it exactly once (no add-gamma
+    # kernel behind the all-reduce)
+    local._consts_override = (model.gamma.item() if (uses_gamma and rank == 0) else 0.0, phase_div)
+    local._dim_shard = (rank, world, model.gamma.item(), uses_gamma)
     return local if device is None else local.to(device)
 
 
@@ -282,8 +285,6 @@ class DimShardedStep:
                 b = hi - lo
                 if work is not None:
                     work.wait()
-                if self.uses_gamma:
-                    scores += self.gamma
                 loss = torch.empty(1, dtype=torch.float32, device=dev)
                 _hip.check(lib.mkb_pool_step_bwd(tb, gr, _hip.ptr(sample[lo:hi]), _hip.ptr(weight[lo:hi]), _hip.ptr(info.pool),
                                                  _hip.ptr(info.cnt[lo:hi]), b, K, mode_id, self.alpha, _hip.ptr(wsum),
