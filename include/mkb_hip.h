@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MKB_ABI_VERSION 1
+#define MKB_ABI_VERSION 3
 
 typedef enum {
     MKB_OK = 0,
@@ -81,8 +81,12 @@ int mkb_check_ids(const int64_t *sample, int64_t B, const int64_t *cand, int64_t
  */
 int mkb_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *cand, int64_t B, int64_t K,
                   int mode, float *score, void *stream);
+/* ws: caller-owned scratch of mkb_score_bwd_workspace_bytes(tb, B, K, mode) bytes, 256-byte aligned (the B*K (row, slot)
+ * pairs radix-sorted by candidate, the queries, the sort's own storage); may be null when that returns 0 (default mode,
+ * K = 1).  Nothing is allocated inside the call. */
+int64_t mkb_score_bwd_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K, int mode);
 int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const int64_t *cand,
-                  int64_t B, int64_t K, int mode, const float *dscore, void *stream);
+                  int64_t B, int64_t K, int mode, const float *dscore, void *ws, void *stream);
 
 /* ---- self-adversarial loss ---------------------------------------------------------------------------
  * mkb_adversarial == losses.Adversarial(alpha)(positive_score, negative_score, weight) AND its gradient

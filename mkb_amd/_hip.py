@@ -14,7 +14,7 @@ import os
 
 # MKB_HIP_LIB selects an experimental build of the same ABI (tools/kbench.py); default = the in-tree product library
 _LIB_PATH = pathlib.Path(os.environ.get("MKB_HIP_LIB") or (pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"))
-ABI_VERSION = 1
+ABI_VERSION = 3  # == MKB_ABI_VERSION of include/mkb_hip.h (bumped whenever a symbol or a signature changes)
 
 MODEL_IDS = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}
 MODE_DEFAULT, MODE_HEAD, MODE_TAIL = 0, 1, 2
@@ -51,8 +51,9 @@ _SIGNATURES = {
     "mkb_abi_version": (c_int, []),
     "mkb_last_error": (c_char_p, []),
     "mkb_score_fwd": (c_int, [POINTER(Tables), c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "mkb_score_bwd_workspace_bytes": (c_int64, [POINTER(Tables), c_int64, c_int64, c_int]),
     "mkb_score_bwd": (c_int, [POINTER(Tables), POINTER(Grads), c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
-                              c_void_p]),
+                              c_void_p, c_void_p]),
     "mkb_adversarial": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_sampler_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_uint32, c_void_p, c_int64, c_void_p,
@@ -112,11 +113,13 @@ def lib():
                 f"{_LIB_PATH} not found: build it with `python -m mkb_amd.csrc.build` "
                 "(mkb_amd has no CPU fallback; the HIP library is the only compute path)")
         handle = ctypes.CDLL(str(_LIB_PATH))
+        handle.mkb_abi_version.restype = c_int
+        if handle.mkb_abi_version() != ABI_VERSION:  # first: a stale build must say so, not fail on a missing symbol later
+            raise HipLibraryError(f"ABI version mismatch: library {handle.mkb_abi_version()}, binding {ABI_VERSION} "
+                                  "(rebuild with `python -m mkb_amd.csrc.build`)")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here = header / library mismatch
             fn.restype, fn.argtypes = res, args
-        if handle.mkb_abi_version() != ABI_VERSION:
-            raise HipLibraryError(f"ABI version mismatch: library {handle.mkb_abi_version()}, binding {ABI_VERSION}")
         _lib = handle
     return _lib
 
@@ -152,6 +155,13 @@ def require_device(*tensors):
 
 def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
+
+
+def aligned_bytes(n, device):
+    """A 256-byte aligned uint8 view of ``n`` bytes of fresh device memory (torch's caching allocator: stream-ordered)."""
+    raw = torch.empty(n + 256, dtype=torch.uint8, device=device)
+    off = (-raw.data_ptr()) % 256
+    return raw[off: off + n]
 
 
 def stream_ptr(device=None):

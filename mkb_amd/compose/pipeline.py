@@ -63,12 +63,26 @@ class Pipeline:
                 and type(loss) is Adversarial and model.entity_embedding.is_cuda
                 and pooled_supported(model, dataset.batch_size, sampling.size)):
             return None
+        self._borrowed = []  # optimizer settings this loop switches on and learn() switches back off before it returns
         if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "draw_ahead", "x") is None:
             optimizer.draw_ahead = sampling  # mkb_amd.optim.Adam: the next pool's draw rides the catch-up launch
+            self._borrowed.append("draw_ahead")
         if getattr(optimizer, "lazy_rows", False) and getattr(optimizer, "defer_step", "x") is None:
             optimizer.defer_step = True  # this loop clears gradients through optimizer.zero_grad() only: the real step of
             #                              the touched rows may wait for the next catch-up launch (mkb_amd/optim.py)
+            self._borrowed.append("defer_step")
         return FusedTrainStep(model, loss.alpha)
+
+    def _give_back(self, optimizer):
+        """Deferral is scoped to learn(): a pending step lives in the table's gradient rows, and the user's own code after
+        learn() may clear gradients any way it likes (model.zero_grad(), p.grad = None) -- so nothing may be left pending and
+        the optimizer goes back to torch.optim semantics (step() applies the step)."""
+        borrowed, self._borrowed = getattr(self, "_borrowed", []), []
+        if "defer_step" in borrowed:
+            optimizer.stop_deferring()   # applies what is pending, then step() launches again
+            optimizer.defer_step = None  # (a later learn() may borrow it again)
+        if "draw_ahead" in borrowed:
+            optimizer.draw_ahead = None
 
     def _run_epoch(self, epoch, fused, model, dataset, sampling, optimizer, loss):
         pending = []  # fused path: losses stay on the device until the bar refreshes (one D2H copy per 10 steps)
@@ -146,6 +160,7 @@ class Pipeline:
             self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
         if hasattr(model, "sync_parameters"):
             model.sync_parameters()  # a row-lazy / deferring optimizer leaves nothing pending behind learn()
+        self._give_back(optimizer)
         return self
 
     @classmethod

@@ -330,41 +330,56 @@ __global__ __launch_bounds__(256) void pair_keys_kernel(const int64_t *__restric
     if (i < n) { keys[i] = (int)cand[i]; vals[i] = i; }
 }
 
+// Scratch of the two-pass backward: queries, the pair list twice (radix sort ping-pong) and the sort's own storage.
+struct Bwd2Scratch {
+    size_t q_bytes, l_bytes, sort_bytes, total;
+    int bits;
+};
+static int bwd2_scratch(const mkb_tables_t *tb, int64_t B, int64_t K, Bwd2Scratch &S) {
+    const int64_t n = B * K;
+    S.bits = 1;
+    while (S.bits < 31 && ((int64_t)1 << S.bits) < tb->n_entity) ++S.bits;
+    S.sort_bytes = 0;
+    MKB_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, S.sort_bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
+                                                     (int *)nullptr, (int)n, 0, S.bits, (hipStream_t)0));
+    S.q_bytes = ((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255;
+    S.l_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+    S.total = S.q_bytes + 4 * S.l_bytes + ((S.sort_bytes + 255) & ~(size_t)255);
+    return MKB_OK;
+}
+static bool bwd2_applies(const mkb_tables_t *tb, const int64_t *cand, int64_t B, int64_t K) {
+    static const bool one_pass = getenv("MKB_GENERAL_ONE_PASS") != nullptr;  // A/B: per-pair atomics
+    return cand && K > 1 && B * K <= INT32_MAX && tb->n_entity <= INT32_MAX && !one_pass;
+}
+
 template <int MODEL>
 static int launch_bwd2(const TablesDev &T, const mkb_tables_t *tb, const mkb_grads_t &G, const int64_t *sample, const int64_t *cand,
-                       int64_t B, int K, bool head, const float *dscore, hipStream_t st) {
+                       int64_t B, int K, bool head, const float *dscore, void *ws, hipStream_t st) {
     const int64_t n = B * K;
-    // stream-ordered scratch: queries, the pair list twice (radix sort ping-pong) and the sort's own storage
-    int bits = 1;
-    while (bits < 31 && ((int64_t)1 << bits) < tb->n_entity) ++bits;
-    size_t sort_bytes = 0;
-    MKB_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const int *)nullptr, (int *)nullptr, (const int *)nullptr,
-                                                     (int *)nullptr, (int)n, 0, bits, st));
-    const size_t q_bytes = ((size_t)B * T.De * 4 + 255) & ~(size_t)255, l_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
-    unsigned char *buf = nullptr;
-    MKB_CHECK_HIP(hipMallocAsync((void **)&buf, q_bytes + 4 * l_bytes + sort_bytes, st));
+    Bwd2Scratch S;
+    if (int rc = bwd2_scratch(tb, B, K, S)) return rc;
+    unsigned char *buf = (unsigned char *)ws;  // caller-owned (mkb_score_bwd_workspace_bytes): nothing is allocated here
+    const size_t q_bytes = S.q_bytes, l_bytes = S.l_bytes;
+    size_t sort_bytes = S.sort_bytes;
+    const int bits = S.bits;
     float *Q = (float *)buf;
     int *k_in = (int *)(buf + q_bytes), *v_in = (int *)(buf + q_bytes + l_bytes), *k_out = (int *)(buf + q_bytes + 2 * l_bytes),
         *v_out = (int *)(buf + q_bytes + 3 * l_bytes);
     void *tmp = buf + q_bytes + 4 * l_bytes;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     hipLaunchKernelGGL(pair_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cand, (int)n, k_in, v_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, k_in, k_out, v_in, v_out, (int)n, 0, bits, st);
-    if (e == hipSuccess) {
-        const unsigned chunks = (unsigned)((n + kChunkPairs - 1) / kChunkPairs);
-        if (head) {
-            hipLaunchKernelGGL((general_query_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, sample, Q);
-            hipLaunchKernelGGL((score_bwd_q_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
-            hipLaunchKernelGGL((score_bwd_x_kernel<MODEL, true>), dim3(chunks), dim3(kBlock), 0, st, T, G, k_out, v_out, (int)n, K, Q, dscore);
-        } else {
-            hipLaunchKernelGGL((general_query_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), 0, st, T, sample, Q);
-            hipLaunchKernelGGL((score_bwd_q_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
-            hipLaunchKernelGGL((score_bwd_x_kernel<MODEL, false>), dim3(chunks), dim3(kBlock), 0, st, T, G, k_out, v_out, (int)n, K, Q, dscore);
-        }
-        e = hipGetLastError();
+    MKB_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, sort_bytes, k_in, k_out, v_in, v_out, (int)n, 0, bits, st));
+    const unsigned chunks = (unsigned)((n + kChunkPairs - 1) / kChunkPairs);
+    if (head) {
+        hipLaunchKernelGGL((general_query_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, sample, Q);
+        hipLaunchKernelGGL((score_bwd_q_kernel<MODEL, true>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
+        hipLaunchKernelGGL((score_bwd_x_kernel<MODEL, true>), dim3(chunks), dim3(kBlock), 0, st, T, G, k_out, v_out, (int)n, K, Q, dscore);
+    } else {
+        hipLaunchKernelGGL((general_query_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), 0, st, T, sample, Q);
+        hipLaunchKernelGGL((score_bwd_q_kernel<MODEL, false>), dim3((unsigned)B), dim3(kBlock), 0, st, T, G, sample, cand, K, dscore);
+        hipLaunchKernelGGL((score_bwd_x_kernel<MODEL, false>), dim3(chunks), dim3(kBlock), 0, st, T, G, k_out, v_out, (int)n, K, Q, dscore);
     }
-    (void)hipFreeAsync(buf, st);
-    MKB_CHECK_HIP(e);
+    MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
 
@@ -426,8 +441,15 @@ extern "C" int mkb_score_fwd(const mkb_tables_t *tb, const int64_t *sample, cons
     return set_error(MKB_ERR_INVALID, "unknown model");
 }
 
+extern "C" int64_t mkb_score_bwd_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K, int mode) {
+    if (!tb || B <= 0 || K <= 1 || mode == MKB_MODE_DEFAULT) return 0;
+    if (B * K > INT32_MAX || tb->n_entity > INT32_MAX) return 0;  // (the one-pass kernel: no scratch)
+    Bwd2Scratch S;
+    return bwd2_scratch(tb, B, K, S) ? -1 : (int64_t)S.total;
+}
+
 extern "C" int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const int64_t *sample, const int64_t *cand,
-                             int64_t B, int64_t K, int mode, const float *dscore, void *stream) {
+                             int64_t B, int64_t K, int mode, const float *dscore, void *ws, void *stream) {
     if (int rc = check_call(tb, sample, cand, B, K, mode)) return rc;
     MKB_REQUIRE(gr && gr->g_ent && gr->g_rel && dscore, "null gradient buffer");
     MKB_REQUIRE(tb->model != MKB_PROTATE || gr->g_modulus, "pRotatE needs g_modulus");
@@ -435,14 +457,15 @@ extern "C" int mkb_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, cons
     const TablesDev T = to_dev(tb);
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode_is_head(mode);
-    static const bool one_pass = getenv("MKB_GENERAL_ONE_PASS") != nullptr;  // A/B: per-pair atomics
-    if (cand && K > 1 && B * K <= INT32_MAX && tb->n_entity <= INT32_MAX && !one_pass) {
+    if (bwd2_applies(tb, cand, B, K)) {
+        MKB_REQUIRE(ws != nullptr && (((uintptr_t)ws) & 255) == 0,
+                    "mkb_score_bwd needs a 256-byte aligned workspace of mkb_score_bwd_workspace_bytes() bytes");
         switch (tb->model) {
-            case MKB_TRANSE: return launch_bwd2<MKB_TRANSE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, st);
-            case MKB_ROTATE: return launch_bwd2<MKB_ROTATE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, st);
-            case MKB_COMPLEX: return launch_bwd2<MKB_COMPLEX>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, st);
-            case MKB_DISTMULT: return launch_bwd2<MKB_DISTMULT>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, st);
-            case MKB_PROTATE: return launch_bwd2<MKB_PROTATE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, st);
+            case MKB_TRANSE: return launch_bwd2<MKB_TRANSE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, ws, st);
+            case MKB_ROTATE: return launch_bwd2<MKB_ROTATE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, ws, st);
+            case MKB_COMPLEX: return launch_bwd2<MKB_COMPLEX>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, ws, st);
+            case MKB_DISTMULT: return launch_bwd2<MKB_DISTMULT>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, ws, st);
+            case MKB_PROTATE: return launch_bwd2<MKB_PROTATE>(T, tb, *gr, sample, cand, B, (int)K, head, dscore, ws, st);
         }
     }
     switch (tb->model) {

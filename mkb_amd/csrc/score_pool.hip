@@ -360,11 +360,20 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
         int npb = 1;
         while (((P + npb - 1) / npb + 63) / 64 > max_halves) npb *= 2;
         while (npb < kMaxSlices && (int64_t)row_tiles * L.dim_slices * npb < 4096 && (P + npb - 1) / npb > 32) npb *= 2;
-        if (const char *q = getenv("MKB_POOL_PBLOCKS")) { const int v = atoi(q); if (v >= npb && v <= kMaxSlices) npb = v; }
+        if (const char *q = getenv("MKB_POOL_PBLOCKS")) { const int v = atoi(q); if (v >= npb && v <= kMaxSlices && (v & (v - 1)) == 0) npb = v; }
         if (npb > kMaxSlices) L.bwd1 = 0;
         if (L.bwd1) {
             L.q_slices = npb;
-            L.pb_halves = (int)(((P + npb - 1) / npb + 63) / 64);
+            // halves: ROUNDED UP to a power of two.  The kernel cuts its 16 chunks into 16 / halves lanes per half, the seed
+            // layout (common.h) shifts by log2(halves), and carve() sizes G / dXp with the same value: 3, 5, 6, 7 would break
+            // all three (e.g. TransE hidden 500, B 2048, K 384: 192 positions per block = 3 halves).  max_halves is a power
+            // of two, so the rounded value still fits the LDS accumulator; slots past P are masked in the kernel.
+            int halves = (int)(((P + npb - 1) / npb + 63) / 64), h2 = 1;
+            while (h2 < halves) h2 *= 2;
+            L.pb_halves = h2;
+            if (h2 > max_halves || (npb & (npb - 1)) != 0) L.bwd1 = 0;  // (cannot happen: both loops above keep the invariants)
+        }
+        if (L.bwd1) {
             const int64_t waves = (int64_t)row_tiles * L.dim_slices * npb;
             L.tiles_per_wave = (int)(waves >= 3 * 4096 ? waves / (2 * 4096) : 1);
             if (const char *q = getenv("MKB_POOL_TPW")) { const int v = atoi(q); if (v >= 1 && v <= 64) L.tiles_per_wave = v; }

@@ -91,6 +91,9 @@ class KdmkbModel:
             self.optimizers[key].step()
             self.optimizers[key].zero_grad()
             self.metrics[key].update(losses[key].item())
+        for key in datasets:  # (the .item() above synchronised already) IndexError for ids outside the tables, like the
+            if hasattr(models[key], "check_ids"):  # reference's index_select raises on the spot
+                models[key].check_ids()
         return self.metrics
 
     def learn(self, models, datasets, max_step, eval_every=2000, update_every=10, log_dir=None, save_path=None):
@@ -104,7 +107,9 @@ class KdmkbModel:
             weight_kl = {k: 0 for k in datasets} if step < self.warm_step else dict(self.alpha_kl)
             metrics = self.forward(datasets, models, weight_kl)
             bar.set_description(text=", ".join(f"{k}: {v.get():4f}" for k, v in metrics.items()))
-            if (step + 1) % self.update_distillation_every == 0:
+            if (step + 1) % self.update_distillation_every == 0 and getattr(self.sampling_method, "depends_on_teacher", True):
+                # (the reference rebuilds to refresh its faiss top-k indexes of the teacher; a teacher-independent sampler
+                # -- UniformSampling -- would only be re-seeded and repeat its draws every update_distillation_every steps)
                 for name in self.distillation:
                     teacher, student = name.split("_", 1) if name.count("_") == 1 else self._split(name, datasets)
                     self.distillation[name] = self._make_distillation(models, datasets, teacher, student)

@@ -10,6 +10,7 @@ __all__ = ["UniformSampling"]
 
 class UniformSampling:
     supervised = True  # the ground truth is part of every distribution
+    depends_on_teacher = False  # nothing to refresh while the teacher trains (KdmkbModel.learn does not rebuild it)
 
     def __init__(self, batch_size_entity, batch_size_relation, seed=None, **kwargs):
         self.batch_size_entity = batch_size_entity

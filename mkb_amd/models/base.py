@@ -63,8 +63,10 @@ class _ScoreFn(torch.autograd.Function):
         tb = model._tables(ent, rel, modulus)
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
         with torch.cuda.device(ent.device):
+            n_ws = _hip.lib().mkb_score_bwd_workspace_bytes(tb, B, K, ctx.mode)  # the glue owns every buffer (mkb_hip.h)
+            ws = _hip.aligned_bytes(n_ws, ent.device) if n_ws > 0 else None
             _hip.check(_hip.lib().mkb_score_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(cand), B, K, ctx.mode,
-                                                _hip.ptr(dscore), _hip.stream_ptr()), "mkb_score_bwd")
+                                                _hip.ptr(dscore), _hip.ptr(ws), _hip.stream_ptr()), "mkb_score_bwd")
         return g_ent, g_rel, g_mod, None, None, None, None
 
 

@@ -188,7 +188,10 @@ def test_pipeline_turns_the_deferred_step_on_and_trains_the_same_model():
 
     e1, r1, o1, l1 = run(None)
     e0, r0, o0, l0 = run(False)
-    assert o1.defer_step is True and o0.defer_step is False
+    # the deferral is scoped to learn(): given back on return, nothing pending, step() applies steps again (torch.optim
+    # semantics for whatever the user's own code does next, e.g. model.zero_grad())
+    assert o1.defer_step is None and o0.defer_step is False and o1.draw_ahead is None
+    assert not any(st.get("defer") for st in o1.state.values())
     assert abs(l1 - l0) < 1e-4
     # The gradients come from fp32 atomics: two runs of the SAME configuration either agree to ~5e-7 or -- when one
     # L1 sign sum cancels to an exact 0 in one order and to a rounding residue in the other -- differ by an lr-sized step in
@@ -197,3 +200,35 @@ def test_pipeline_turns_the_deferred_step_on_and_trains_the_same_model():
     for a, b in ((e1, e0), (r1, r0)):
         diff = (a - b).abs()
         assert int((diff > 2e-5).sum()) <= 32 and float(diff.max()) < 1e-2, (int((diff > 2e-5).sum()), float(diff.max()))
+
+
+def test_user_code_after_learn_may_clear_gradients_any_way_it_likes():
+    """After learn() the optimizer is back to plain semantics: a hand-written step that clears gradients with
+    model.zero_grad(set_to_none=True) must lose nothing (with a pending deferred step it would silently drop one)."""
+    from mkb_amd import compose, datasets, losses, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    def run(borrow):
+        ds = datasets.Fb15k237(batch_size=2048, shuffle=True, seed=42, num_workers=0)
+        db = datasets.DeviceBatches(ds, "cuda", seed=42)
+        torch.manual_seed(42)
+        m = models.TransE(hidden_dim=16, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+        opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, lazy_rows=True, defer_step=None if borrow else False)
+        ds.valid, ds.test = [], []
+        compose.Pipeline(epochs=1, eval_every=100, device="cuda").learn(model=m, dataset=db, sampling=ns, optimizer=opt,
+                                                                        loss=losses.Adversarial(alpha=1.0))
+        before = m.entity_embedding.detach().clone()
+        step = FusedTrainStep(m, 1.0)
+        s = torch.as_tensor(np.asarray(ds.train[:512], dtype=np.int64)).cuda()
+        w = torch.ones(512, device="cuda")
+        for _ in range(2):  # the user's own loop
+            step(s, w, ns.generate(s, "tail-batch"), "tail-batch")
+            opt.step()
+            m.zero_grad(set_to_none=True)
+        opt.flush()
+        moved = (m.entity_embedding.detach() - before).abs().max().item()
+        return moved
+
+    a, b = run(True), run(False)
+    assert a > 0 and abs(a - b) < 1e-6, (a, b)

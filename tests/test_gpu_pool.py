@@ -190,6 +190,89 @@ def test_full_size_fused_step_gradients_vs_oracle_on_a_128_row_slice(name):
     ns.check()
 
 
+def _weighted_slice_step(cls, name, hidden, B, K, n_rows, gamma, alpha, seed=11):
+    """Fused step over B rows of which only `n_rows` carry weight, against the oracle's step over those rows alone (the
+    argument of test_full_size_fused_step_gradients_vs_oracle_on_a_128_row_slice)."""
+    from mkb_amd import datasets, models, sampling
+    from mkb_amd.fused import FusedTrainStep
+    from oracle import scoring
+
+    ds = getattr(datasets, cls)(batch_size=B, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(seed)
+    m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=gamma)
+    tb = scoring.Tables(name, hidden, gamma, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(),
+                        m.modulus.detach().clone() if hasattr(m, "modulus") else None)
+    m = m.cuda()
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64))
+    idx = torch.as_tensor(np.random.RandomState(9).randint(len(train), size=B))
+    s = train[idx].cuda()
+    half = n_rows // 2
+    rows = torch.cat([torch.arange(half), torch.arange(half, B, (B - half) // half)[:half]])
+    assert len(rows) == n_rows
+    w = torch.zeros(B)
+    w[rows] = torch.rand(n_rows) + 0.1
+    for mode in ("head-batch", "tail-batch"):
+        neg = ns.generate(s, mode)
+        m.zero_grad(set_to_none=True)
+        step = FusedTrainStep(m, alpha=alpha)
+        loss = step(s, w.cuda(), neg, mode)
+        ref = scoring.train_step_grads(tb, s.cpu()[rows], neg.cpu()[rows], w[rows], mode, alpha, fast_norm=True)
+        np.testing.assert_allclose(step.positive_score.cpu()[rows].numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(step.negative_score.cpu()[rows].numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        if name == "pRotatE":
+            np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
+    ns.check()
+
+
+def test_config2_full_size_fused_step_vs_oracle():
+    """BASELINE configs[1] at FULL size: WN18RR, RotatE hidden 500, K = 128, B = 1024 (reference shape:
+    mkb/datasets/wn18rr.py:44-47), loss and both dense gradients against the oracle on a 128-row slice."""
+    _weighted_slice_step("Wn18rr", "RotatE", 500, 1024, 128, 128, gamma=6.0, alpha=0.5)
+
+
+def test_config2_full_size_pooled_equals_general():
+    """configs[1] at full size, all 1024 rows weighted: the pooled route (shared-pool kernels) and the general route
+    (arbitrary-candidate kernels + autograd) must agree on scores, loss and both gradients."""
+    from mkb_amd import losses
+
+    B, K = 1024, 128
+    ds, m, tb, ns, train = _setup("Wn18rr", "RotatE", 500, B, K, gamma=6.0)
+    idx = torch.as_tensor(np.random.RandomState(3).randint(len(train), size=B))
+    s = train[idx].cuda()
+    w = (torch.rand(B) + 0.1).cuda()
+    for mode in ("head-batch", "tail-batch"):
+        neg = ns.generate(s, mode)
+        plain = neg.clone()
+        got = {}
+        for tag, n in (("pooled", neg), ("general", plain)):
+            m.zero_grad(set_to_none=True)
+            sc = m(s, n, mode)
+            err = losses.Adversarial(alpha=0.5)(m(s), sc, w)
+            err.backward()
+            got[tag] = (sc.detach().cpu().numpy(), err.item(), m.entity_embedding.grad.cpu().numpy().copy(),
+                        m.relation_embedding.grad.cpu().numpy().copy())
+        np.testing.assert_allclose(got["pooled"][0], got["general"][0], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(got["pooled"][1], got["general"][1], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got["pooled"][2], got["general"][2], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(got["pooled"][3], got["general"][3], rtol=1e-4, atol=1e-5)
+    ns.check()
+
+
+@pytest.mark.parametrize("name,hidden,B,K", [
+    ("TransE", 500, 2048, 384),    # 768 positions / 4 blocks = 192 per block = 3 halves of 64 (rounded up to 4)
+    ("pRotatE", 500, 2048, 384),
+    ("TransE", 200, 2048, 300),    # 600 positions: 5 halves at one block per 8-half accumulator
+])
+def test_single_pass_backward_position_blocks_not_a_power_of_two(name, hidden, B, K):
+    """Shapes whose position blocks hold 3, 5, 6 or 7 sixty-four-slot halves: the host rounds the halves up to a power of
+    two (kernel chunking, seed layout and workspace sizes all assume one); the gradients must still match the oracle."""
+    _weighted_slice_step("Fb15k237", name, hidden, B, K, 64, gamma=9.0, alpha=1.0)
+
+
 @pytest.mark.parametrize("fuse", [True, False])
 def test_pipeline_countries_vs_reference_capture(golden, fuse, capsys):
     """compose/pipeline.py:79-129 setup: CountriesS1 bs=20 seed 42, RotatE hidden 5 gamma 3, K=4, Adam 5e-5,
