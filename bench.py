@@ -12,9 +12,14 @@ and scores B*(K+1) = 263,168 triples per GPU.  Inputs (training triples, subsamp
 state) are resident in HBM before the timed region; batches are index-selected on the device.
 
 Multi-GPU (N > 1), weak scaling with a global batch of N*1024 rows scored against ONE candidate pool (replicated
-MT19937 state).  Default --parallelism dims: the embedding DIMENSION is sharded (rank g holds 1/N of every table
-column-wise, 1/N of the optimizer state); every rank scores all N*1024 rows on its dims, ONE RCCL all-reduce of the
-partial scores [N*1024, 2K+1] per step, then loss / backward / Adam are local -- no gradient exchange.
+MT19937 state).  Default --parallelism table-rows, the partitioning BASELINE.json's north_star names: the entity table, its
+gradient and its Adam state are sharded by ROW (owner = id % N, mkb_amd/table_rows.py); pool rows by one all-reduce,
+positive rows by all-to-all, gradients back the same way, row-lazy Adam per shard.  The same run then measures the two
+alternatives (fewer steps) and BASELINE configs[4] (YAGO3-10 RotatE-500, the config north_star shards) and reports them
+under "other_partitionings" / "config5" of the same JSON line:
+--parallelism dims: the embedding DIMENSION is sharded (rank g holds 1/N of every table column-wise, 1/N of the optimizer
+state); every rank scores all N*1024 rows on its dims, ONE RCCL all-reduce of the partial scores [N*1024, 2K+1] per step,
+then loss / backward / Adam are local -- no gradient exchange.
 --parallelism rows: batch-row data parallel with replicated tables and a sparse all-reduce of the touched gradient
 rows (mkb_amd.parallel.SparseGradExchange).
 
@@ -67,7 +72,7 @@ def load_fb15k237():
     return tr, n_ent, n_rel
 
 
-def build(device, rank, world, seed=42, parallelism="dims"):
+def build(device, rank, world, seed=42, parallelism="table-rows", force=False):
     from mkb_amd import models, optim, parallel, sampling
     from mkb_amd.datasets.base import subsampling_weights
     from mkb_amd.fused import FusedTrainStep
@@ -77,7 +82,7 @@ def build(device, rank, world, seed=42, parallelism="dims"):
     torch.manual_seed(seed)
     model = getattr(models, MODEL)(hidden_dim=HIDDEN, entities=ents, relations=rels, gamma=GAMMA)
     dims = world > 1 and parallelism == "dims"
-    trows = world > 1 and parallelism == "table-rows"
+    trows = (world > 1 or force) and parallelism == "table-rows"  # force: the sharded code path on one GPU (no collective runs)
     table = rel_rep = None
     if trows:  # entity table, its gradient and its Adam state sharded by ROW (owner = id % world); relation table replicated
         from mkb_amd.table_rows import TableRowShardedStep, shard_table_rows
@@ -90,7 +95,11 @@ def build(device, rank, world, seed=42, parallelism="dims"):
     # MKB_BENCH_DENSE_ADAM=1 selects the plain dense streaming kernel instead
     lazy = os.environ.get("MKB_BENCH_DENSE_ADAM", "0") != "1"
     if trows:
-        opt = optim.Adam([table.data, rel_rep], lr=LR)  # dense Adam on this rank's shard: no optimizer communication
+        # the shard steps like the single-GPU table: dense-Adam semantics evaluated row-lazily, real step deferred into the
+        # next step's catch-up launch (which also draws the sampler's next pool); no optimizer communication
+        opt = optim.Adam([table.data, rel_rep], lr=LR, lazy_rows=lazy,
+                         draw_ahead=sampler if os.environ.get("MKB_BENCH_NO_DRAW_AHEAD", "0") != "1" else None,
+                         defer_step=lazy and os.environ.get("MKB_BENCH_NO_DEFER", "0") != "1")
         step = TableRowShardedStep(table, rel_rep, ALPHA, model_cls=getattr(models, MODEL), hidden_dim=HIDDEN, gamma=GAMMA)
     else:
         opt = optim.Adam([p for p in model.parameters() if p.requires_grad and (MODEL != "RotatE" or p is not model.modulus)],
@@ -115,7 +124,8 @@ def run_step(ctx, i):
     if ctx.get("trows"):  # row-sharded entity table: this rank's rows of the global batch, ONE shared pool (replicated RNG)
         lo = ((i * world + rank) * Bl) % (n - Bl)
         sample, weight = ctx["train"][lo: lo + Bl], ctx["weights"][lo: lo + Bl]
-        loss = ctx["step"](sample, weight, ctx["sampler"].generate(sample, mode), mode)
+        nlo = (((i + 1) * world + rank) * Bl) % (n - Bl)  # the next batch: its routing is prepared while this step runs
+        loss = ctx["step"](sample, weight, ctx["sampler"].generate(sample, mode), mode, next_sample=ctx["train"][nlo: nlo + Bl])
         ctx["opt"].step()
         ctx["opt"].zero_grad()
         return loss
@@ -175,7 +185,7 @@ def train_and_rank(ctx, epochs, first_step):
                     "literature RotatE on FB15k-237 reaches MRR ~0.34 after long training"}
 
 
-def cpu_baseline(rows=64, rows_sqrt=128, seed=42, warmup=1, timed=2):
+def cpu_baseline(rows=64, rows_sqrt=128, seed=42, warmup=2, timed=3):
     """The oracle (torch-CPU restatement of the reference path) timed on the host cores, by BASELINE.md section 3's
     protocol on a bounded sample: `warmup` untimed + `timed` timed steps over `rows` rows of a headline batch (full
     tables, same K / dims), each phase timed on its own -- sample (the plain-C sampler restatement), fwd (positive +
@@ -303,6 +313,254 @@ def step_variants(ctx, steps=60):
     return out
 
 
+# rocprofv3 kernel-name fragments of the profiled classes (the in-run HBM traffic measurement matches on them)
+KERNEL_NAMES = {"pool_fwd": ("pool_fwd", "pair_fwd", "gemm"), "pool_bwd_q": ("pool_bwd1", "pair_bwd", "pool_bwd_kernel", "gemm"),
+                "adam": ("adam_rows_catchup_kernel", "adam_kernel"), "pool_bwd_x": ("gemm",)}
+
+
+def measure_traffic(prof_kind, config):
+    """HBM bytes per launch of the profiled kernel class, measured NOW: two short rocprofv3 PMC passes (FETCH_SIZE, then
+    WRITE_SIZE: the TCC has 4 slots, the two counters need 5) over this same script, as MI355X_MICROARCH.md's HBM section
+    prescribes; FETCH_SIZE doubled (gfx950 tallies a 128-byte request as 64 bytes for wide coalesced reads: calibrated on
+    the dense Adam kernel in round 1), KiB -> bytes.  Returns (bytes or None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    frags = KERNEL_NAMES.get(prof_kind)
+    if not frags:
+        return None, f"no kernel name known for class {prof_kind}"
+    out, notes = {}, []
+    tmp = tempfile.mkdtemp(prefix="mkb_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MKB_BENCH_INNER="1")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "12", "--warmup", "4", "--config", config, "--no-cpu-baseline", "--mrr-epochs", "0", "--no-variants",
+                   "--profile-kernel", "none", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            per = {}
+            for name, val in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+                a = per.setdefault(name, [0, 0.0])
+                a[0] += 1
+                a[1] += val
+            best = None
+            for frag in frags:  # first fragment that matches; the heaviest kernel of that name
+                hit = [(tot / n, n, name) for name, (n, tot) in per.items() if frag in name]
+                if hit:
+                    best = max(hit)
+                    break
+            if best is None:
+                return None, f"no kernel matching {frags} in the {counter} pass"
+            out[counter] = best[0] * 1024.0  # KiB per dispatch -> bytes
+            notes.append(f"{counter} {best[0] * 1024 / 1e6:.1f} MB x {best[1]} launches of {best[2][:60]}")
+    except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment: never lose the bench line over it
+        return None, f"traffic pass failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+    return total, ("measured in this run: rocprofv3 --pmc, separate passes over 12 steps; 2 x FETCH_SIZE + WRITE_SIZE, mean per launch: "
+                   + "; ".join(notes))
+
+
+def measure(args, device, rank, world, config, parallelism, steps, warmup, profile=True, force=False):
+    """Build `config` under `parallelism`, warm up, time exactly `steps` steps between barriers (max over ranks).
+    -> dict with the context, the timing and the HIP-event timing of the dominant kernel class."""
+    import torch.distributed as dist
+    from mkb_amd import _hip
+
+    globals().update(CONFIGS[config])
+    ctx = build(device, rank, world, parallelism=parallelism, force=force)
+    ctx["rows_per_rank"] = B if (args.scaling == "weak" or world == 1) else max(8, B // world)
+    if world > 1 and not ctx["dims"] and not ctx["trows"]:
+        from mkb_amd import parallel
+
+        ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], equal_batches=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kinds = ["pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam", "sampler", "loss", "general_fwd", "general_bwd"]
+    for i in range(warmup):
+        run_step(ctx, i)
+    barrier()
+    prof_kind = args.profile_kernel if profile else "none"
+    if prof_kind == "auto":  # pick the dominant kernel class on a short probe
+        for k in kinds:
+            _hip.profile_enable(k, True)
+        for i in range(8):
+            run_step(ctx, warmup + i)
+        torch.cuda.synchronize()
+        tot = {}
+        for k in kinds:
+            n, ms = _hip.profile_read(k)
+            tot[k] = ms
+            _hip.profile_enable(k, False)
+        prof_kind = max(("pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam"), key=lambda k: tot[k])
+        if args.breakdown and rank == 0:
+            print("probe ms/step by kernel class:", {k: round(v / 8, 4) for k, v in tot.items()}, file=sys.stderr)
+    if prof_kind != "none":
+        # every 5th launch of the class is bracketed with HIP events inside the timed region (odd stride: head- and tail-batch
+        # steps are both sampled); each bracket costs ~12 us of stream time, so bracketing every launch would tax every step
+        _hip.profile_enable(prof_kind, 5)
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = run_step(ctx, warmup + 8 + i)
+    ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
+    t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if args.breakdown and rank == 0:
+        print(f"host enqueue {t_host / steps * 1e3:.4f} ms/step of {dt / steps * 1e3:.4f} ms/step", file=sys.stderr)
+    sampler_note = None
+    try:
+        ctx["sampler"].check()
+    except RuntimeError as e:  # a row whose true set covers the whole pool (dense toy graphs): the reference would hang
+        if config == "headline":
+            raise
+        sampler_note = f"sampler: {e}"
+    assert torch.isfinite(loss).item() or sampler_note
+    if world > 1:  # rows: replicas must hold identical tables; dims / table-rows: every rank must report the same global loss
+        probe = (loss.detach().double().reshape(1) if (ctx["dims"] or ctx["trows"])
+                 else ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1))
+        lo_, hi_ = probe.clone(), probe.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        # the all-reduced scores / loss are bitwise equal on every rank with ring / tree all-reduce; allow for algorithms
+        # that are not (rel. 1e-5) instead of aborting the run.  rows: replicas apply identical updates.
+        assert abs(hi_.item() - lo_.item()) <= 1e-5 * max(1.0, abs(hi_.item())), "data-parallel replicas diverged"
+    launches, kms = (0, 0.0)
+    if prof_kind != "none":
+        launches, kms = _hip.profile_read(prof_kind)
+        _hip.profile_enable(prof_kind, False)
+    return dict(ctx=ctx, dt=dt, steps=steps, warmup=warmup, loss=float(loss.item()), launches=launches, kms=kms, prof_kind=prof_kind,
+                sampler_note=sampler_note, config=config, t_host=t_host,
+                value=world * ctx["rows_per_rank"] * (K + 1) * steps / dt, ms_per_step=dt / steps * 1e3)
+
+
+def parallelism_label(ctx, world):
+    if world == 1 and not ctx["trows"]:
+        return "single"
+    if ctx["dims"]:
+        return f"dims{world} (embedding dimension sharded, 1 score all-reduce/step)"
+    if ctx["trows"]:
+        return (f"table-rows{world} (entity table + gradient + row-lazy Adam state sharded by row; pool rows all-reduce, positive "
+                "rows all-to-all, routes planned one batch ahead)")
+    return f"dp{world} (rows, sparse grad all-reduce)"
+
+
+def roofline_of(res, world, want_traffic):
+    """The `roofline` object of the JSON line for the kernel class that was HIP-event timed inside the timed region."""
+    ctx, prof_kind, launches = res["ctx"], res["prof_kind"], res["launches"]
+    if not launches:
+        return None
+    m_ = ctx["model"]
+    De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation  # per rank (dims: 1/world of the row)
+    Bk = world * ctx["rows_per_rank"] if ctx["dims"] else ctx["rows_per_rank"]  # rows each rank's kernels see
+    avg_s = res["kms"] / launches / 1e3
+    traffic, traffic_note = (None, "not measured (--no-traffic, N > 1, or a non-default run)")
+    if want_traffic:
+        traffic, traffic_note = measure_traffic(prof_kind, res["config"])
+    info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
+    if prof_kind == "adam":
+        lazy_rows = getattr(ctx["opt"], "lazy_rows", False)
+        if lazy_rows:
+            # row-lazy advance launch: the DISTINCT rows the batch touches x (p, m, v, g read + p, m, v, g written) x 4 B,
+            # plus the relation table's dense step that rides it
+            ids = info.touched if info.touched is not None else torch.cat([info.pool, ctx["train"][:Bk, 0], ctx["train"][:Bk, 2]])
+            rows = int(torch.unique(ids).numel())
+            alg = 8 * 4 * (rows * De + R * Dr)
+            note = (f"row-lazy Adam advance launch: {rows} distinct touched rows x {De} floats x (p, m, v, g in + p, m, v, 0 -> g out) "
+                    f"+ the dense relation-table step riding it")
+        else:
+            alg = 8 * 4 * (N * De + R * Dr) / 2.0  # one launch per parameter tensor, averaged over the two
+            note = "dense Adam (+zero_grad) kernel: 8 x 4 B per parameter element, averaged over the ent/rel launches"
+        ach = alg / avg_s / 1e9
+        return {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "avg_kernel_us": avg_s * 1e6,
+                "launches": launches, "algorithmic_bytes_per_launch": alg, "note": note}
+    # The pooled kernels reuse every candidate row from registers / LDS / L2 (PMC traffic is ~1/30 of the logical gather
+    # bytes), so HBM does not bound them: the fp32 VALU + the quarter-rate transcendental pipe do (DESIGN.md section 5).
+    # achieved = ALGORITHMIC flop per launch (every used (row, pool position, dim) pair term evaluated ONCE; flop per
+    # term from the instruction sequence in model_math.h) / mean launch duration, against the 157.3 TFLOP/s fp32
+    # vector peak of MI355X_MICROARCH.md.  The MFMA route of the bilinear models is priced as its GEMM over the USED part of
+    # the pool (positions some row uses), not over the padded launch.
+    used = (info.cnt.to(torch.int32) > 0)
+    pairs = int(used.sum().item())                      # (row, pool position) pairs the batch really uses
+    p_used = int(used.any(dim=0).sum().item())          # pool positions at least one row uses (P' of SURVEY 8d)
+    units = m_.hidden_dim if MODEL == "RotatE" else De  # pair terms per (row, position)
+    bwd = prof_kind != "pool_fwd"
+    per_term = {"RotatE": ((6, 1), (15, 1)), "TransE": ((2, 0), (4, 0)), "pRotatE": ((4, 1), (9, 2)),
+                "ComplEx": ((2, 0), (4, 0)), "DistMult": ((2, 0), (4, 0))}[MODEL][1 if bwd else 0]
+    mfma = MODEL in ("ComplEx", "DistMult")
+    if mfma:  # S = Q.X^T | dQ = G.X | dX = G^T.Q over [B, P'] -- algorithmic: the columns somebody uses
+        flop, trans = 2.0 * Bk * p_used * De, 0.0
+    else:
+        flop, trans = float(pairs) * units * per_term[0], float(pairs) * units * per_term[1]
+    ach = flop / avg_s / 1e12
+    label = "pool_bwd (single pass: dq and dx from one evaluation of every pair term)" if bwd else "pool_fwd"
+    roof = {"bound": "mfma" if mfma else "valu", "kernel": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+            "avg_kernel_us": avg_s * 1e6, "launches": launches, "algorithmic_flop_per_launch": flop,
+            "note": (f"{label}: " + (f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}"
+                                     if mfma else f"{pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop")
+                     + "; peak = fp32 vector / matrix rate of MI355X")}
+    if MODEL == "TransE":
+        roof["bound_note"] = ("2-4 flop per 4-byte pair term: the kernel is bound by moving operands (L2 -> registers, LDS "
+                              "read-modify-write of dx), not by the VALU; the fraction of the fp32 peak is reported for continuity only")
+    if trans:
+        t_rate = trans / avg_s / 1e12
+        roof.update({"transcendental_rate_Tops": t_rate, "transcendental_peak_Tops": TRANS_PEAK_TOPS,
+                     "transcendental_frac": t_rate / TRANS_PEAK_TOPS,
+                     # issue-slot view: fp32 ops 2 cycles per wave and 64 results (SIMD-32), v_rsq / v_sqrt 8
+                     "issue_frac": (flop / 2.0 / 32.0 + trans / 8.0) / (1024 * 2.4e9) / avg_s})
+    # secondary: SURVEY 8(d)'s logical gather bytes (what the reference formulation would move) -- a REUSE figure, may
+    # exceed the HBM peak; never a roofline fraction
+    roof["logical_gather_GBps"] = (2 if bwd else 1) * Bk * K * De * 4 / avg_s / 1e9
+    return roof
+
+
+def step_roofline(res, world):
+    """Whole-step view: the step's algorithmic flop and its compulsory HBM bytes over ms_per_step."""
+    ctx = res["ctx"]
+    m_ = ctx["model"]
+    De = m_.entity_dim
+    Bk = ctx["rows_per_rank"]
+    info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
+    ids = info.touched if info.touched is not None else torch.cat([info.pool, ctx["train"][:Bk, 0], ctx["train"][:Bk, 2]])
+    rows = int(torch.unique(ids).numel())
+    flop_per = {"RotatE": 16 * m_.hidden_dim, "TransE": 6 * De, "pRotatE": 13 * De, "ComplEx": 6 * De, "DistMult": 6 * De}[MODEL]
+    flop = float(Bk) * K * flop_per
+    # compulsory: every distinct touched row is read once by the step (forward) and moves once through the optimizer
+    # (p, m, v, g in; p, m, v, cleared g out): 9 row passes
+    byts = 9.0 * rows * De * 4
+    s = res["ms_per_step"] / 1e3
+    return {"algorithmic_flop_per_step": flop, "achieved_TFLOPs": flop / s / 1e12, "frac_of_fp32_peak": flop / s / 1e12 / FP32_PEAK_TFLOPS,
+            "compulsory_hbm_bytes_per_step": byts, "compulsory_GBps": byts / s / 1e9, "frac_of_hbm_peak": byts / s / 1e9 / HBM_PEAK_GBS,
+            "distinct_touched_rows": rows,
+            "note": f"SURVEY 8(d): B*K*{flop_per} flop per step (fwd + bwd, per rank); compulsory bytes = {rows} distinct touched rows x "
+                    f"{De * 4} B x 9 passes (1 read by the step + p, m, v, g in / out through the optimizer); both over ms_per_step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,21 +569,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the cpu_baseline sample (reference-faithful form)")
     ap.add_argument("--no-variants", action="store_true", help="skip the with/without optimizer & sampler step variants")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-extras", action="store_true", help="N>1: skip the other partitionings and config 5")
     ap.add_argument("--profile-kernel", default="auto", help="kernel class bracketed with HIP events (or 'none')")
     ap.add_argument("--breakdown", action="store_true", help="also print per-phase timings (stderr)")
     ap.add_argument("--scaling", default=os.environ.get("MKB_BENCH_SCALING", "weak"), choices=["weak", "strong"],
                     help="N>1: weak = 1024 rows per GPU (global batch N*1024); strong = global batch fixed at 1024 rows")
-    ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "dims"), choices=["dims", "rows", "table-rows"],
-                    help="N>1: 'dims' = shard the embedding dimension (one all-reduce of partial scores per step, no "
-                         "gradient exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce; 'table-rows' = "
-                         "entity table + gradient + Adam state sharded by row (BASELINE config 5's partitioning): pool rows by "
-                         "all-reduce, positive rows by all-to-all, gradients back the same way")
+    ap.add_argument("--parallelism", default=os.environ.get("MKB_BENCH_PARALLELISM", "table-rows"), choices=["dims", "rows", "table-rows"],
+                    help="N>1: 'table-rows' (default) = entity table + gradient + Adam state sharded by row (north_star's / BASELINE "
+                         "config 5's partitioning): pool rows by all-reduce, positive rows by all-to-all, gradients back the same "
+                         "way; 'dims' = shard the embedding dimension (one all-reduce of partial scores per step, no gradient "
+                         "exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce")
+    ap.add_argument("--force-parallelism", action="store_true",
+                    help="N=1: run the table-rows code path on the one GPU (world 1, no collective): the per-rank compute of that path")
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (default: the headline; the others are for profiles/)")
     ap.add_argument("--mrr-epochs", type=int, default=10,
                     help="after the timed region (N=1 only): train this many more epochs, then filtered MRR on the test set")
     args = ap.parse_args()
-    globals().update(CONFIGS[args.config])
     if args.config != "headline":
         args.mrr_epochs, args.no_cpu_baseline = 0, True
 
@@ -340,6 +601,7 @@ def main():
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -348,170 +610,102 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    from mkb_amd import _hip
 
-    ctx = build(device, rank, world, parallelism=args.parallelism)
-    ctx["rows_per_rank"] = B if (args.scaling == "weak" or world == 1) else max(8, B // world)
-    if world > 1 and not ctx["dims"] and not ctx["trows"]:
-        from mkb_amd import parallel
+    # ---- the line's own measurement.  N > 1: the north_star partitioning first; should it fail on every rank alike (an
+    # RCCL feature missing on the box), fall back rather than lose the line -- the failure is reported in the line.
+    order = [args.parallelism] + ([p for p in ("dims", "rows") if p != args.parallelism] if world > 1 else [])
+    res, failures = None, {}
+    for par in order:
+        try:
+            res = measure(args, device, rank, world, args.config, par, args.steps, args.warmup, force=args.force_parallelism)
+            break
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            failures[par] = f"{type(e).__name__}: {str(e)[:300]}"
+            print(f"[bench] rank {rank}: parallelism {par} failed: {failures[par]}", file=sys.stderr)
+            torch.cuda.synchronize()
+    if res is None:
+        raise SystemExit(f"every partitioning failed: {failures}")
+    ctx = res["ctx"]
 
-        ctx["exchange"] = parallel.SparseGradExchange(ctx["model"], equal_batches=True)
+    out = None
+    if rank == 0:
+        if res["sampler_note"]:
+            print(res["sampler_note"], file=sys.stderr)
+        default_run = world == 1 and not os.environ.get("MKB_BENCH_INNER")
+        out = {
+            "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
+            else f"scored triples/sec (pos+K neg), {args.config}", "value": res["value"], "unit": "triples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": (f"{DATASET} train triples (packaged asset" + ("; SYNTHETIC triples: train.csv absent upstream" if DATASET == "yago310" else "")
+                     + "), random-init tables (torch.manual_seed(42)), synthetic batch order"),
+            "config": {"workload": ("BASELINE configs[2]: " if args.config == "headline" else f"{args.config}: ")
+                                   + f"datasets.{DATASET} + models.{MODEL} hidden_dim={HIDDEN}, K={K}, batch {B}/GPU, "
+                                   f"Adversarial alpha={ALPHA}, gamma={GAMMA}, dense Adam lr={LR} (row-lazy exact evaluation); "
+                                   "step = sampler + pos/neg forward + loss + backward + Adam",
+                       "global_batch": world * ctx["rows_per_rank"], "negatives": K,
+                       "parallelism": parallelism_label(ctx, world)},
+            "loss": res["loss"],
+            "roofline": roofline_of(res, world, want_traffic=default_run and not args.no_traffic and res["prof_kind"] != "none"),
+        }
+        if out["roofline"] is not None:
+            out["roofline"]["step"] = step_roofline(res, world)
+        if failures:
+            out["partitioning_failures"] = failures
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # ---- N > 1: the other partitionings and BASELINE configs[4] in the same run (fewer steps; same barrier + max-over-ranks
+    # timing).  A watchdog prints the line without them if they hang: the headline number must not be lost to an extra.
+    if world > 1 and not args.no_extras and not failures:
+        import threading
 
-    kinds = ["pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam", "sampler", "loss", "general_fwd", "general_bwd"]
-    # pick the dominant kernel class on a short probe unless told otherwise
-    for i in range(args.warmup):
-        run_step(ctx, i)
-    barrier()
-    prof_kind = args.profile_kernel
-    merged_bwd = MODEL not in ("ComplEx", "DistMult")
-    if prof_kind == "auto":
-        for k in kinds:
-            _hip.profile_enable(k, True)
-        for i in range(8):
-            run_step(ctx, args.warmup + i)
-        torch.cuda.synchronize()
-        tot = {}
-        for k in kinds:
-            n, ms = _hip.profile_read(k)
-            tot[k] = ms
-            _hip.profile_enable(k, False)
-        prof_kind = max(("pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam"), key=lambda k: tot[k])
-        merged_bwd = tot["pool_bwd_x"] == 0.0  # VALU models: the dq and dx passes are one launch, timed as pool_bwd_q
-        if args.breakdown and rank == 0:
-            print("probe ms/step by kernel class:", {k: round(v / 8, 4) for k, v in tot.items()}, file=sys.stderr)
-    if prof_kind != "none":
-        # every 5th launch of the class is bracketed with HIP events inside the timed region (odd stride: head- and tail-batch
-        # steps are both sampled); each bracket costs ~12 us of stream time, so bracketing every launch would tax every step
-        _hip.profile_enable(prof_kind, 5)
+        def bail():
+            if rank == 0:
+                out["extras_error"] = "extras timed out"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = run_step(ctx, args.warmup + 8 + i)
-    ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
-    t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    if args.breakdown and rank == 0:
-        print(f"host enqueue {t_host / args.steps * 1e3:.4f} ms/step of {dt / args.steps * 1e3:.4f} ms/step", file=sys.stderr)
-    sampler_note = None
-    try:
-        ctx["sampler"].check()
-    except RuntimeError as e:  # a row whose true set covers the whole pool (dense toy graphs): the reference would hang
-        if args.config == "headline":
-            raise
-        sampler_note = f"sampler: {e}"
-    assert torch.isfinite(loss).item() or sampler_note
-    if world > 1:  # rows: replicas must hold identical tables; dims: every rank must have computed the same loss
-        probe = (loss.detach().double().reshape(1) if (ctx["dims"] or ctx["trows"])
-                 else ctx["model"].entity_embedding.detach()[::97].double().sum().reshape(1))
-        lo_, hi_ = probe.clone(), probe.clone()
-        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
-        # dims: the all-reduced scores (hence the loss) are bitwise equal on every rank with ring / tree all-reduce; allow
-        # for algorithms that are not (rel. 1e-5) instead of aborting the run.  rows: replicas apply identical updates.
-        assert abs(hi_.item() - lo_.item()) <= 1e-5 * max(1.0, abs(hi_.item())), "data-parallel replicas diverged"
-
-    launches, kms = (0, 0.0)
-    if prof_kind != "none":
-        launches, kms = _hip.profile_read(prof_kind)
-        _hip.profile_enable(prof_kind, False)
+        dog = threading.Timer(float(os.environ.get("MKB_BENCH_EXTRAS_TIMEOUT", "300")), bail)
+        dog.daemon = True
+        dog.start()
+        main_par = "table-rows" if ctx["trows"] else ("dims" if ctx["dims"] else "rows")
+        del ctx
+        res["ctx"] = None
+        e_steps, e_warm = min(args.steps, 60), min(args.warmup, 10)
+        extras, cfg5 = {}, None
+        try:
+            for par in ("table-rows", "dims", "rows"):
+                if par == main_par:
+                    continue
+                r = measure(args, device, rank, world, args.config, par, e_steps, e_warm, profile=False)
+                extras[par] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": e_steps, "warmup": e_warm, "loss": r["loss"]}
+                r["ctx"] = None
+            if args.config == "headline":
+                r = measure(args, device, rank, world, "yago310-rotate", "table-rows", e_steps, e_warm, profile=False)
+                cfg5 = {"workload": "BASELINE configs[4]: datasets.Yago310 (123,182 entities; SYNTHETIC train triples, train.csv absent "
+                                    f"upstream) + RotatE hidden_dim=500, K=256, batch 1024/GPU, entity table row-sharded over {world} GPUs",
+                        "value": r["value"], "unit": "triples/s", "ms_per_step": r["ms_per_step"], "steps": e_steps, "warmup": e_warm,
+                        "loss": r["loss"], "parallelism": parallelism_label(r["ctx"], world)}
+                r["ctx"] = None
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                out["extras_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+        dog.cancel()
+        globals().update(CONFIGS[args.config])
+        if rank == 0:
+            out["other_partitionings"] = extras
+            if cfg5 is not None:
+                out["config5"] = cfg5
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    if sampler_note:
-        print(sampler_note, file=sys.stderr)
-    triples_per_step = world * ctx["rows_per_rank"] * (K + 1)
-    value = triples_per_step * args.steps / dt
-    m_ = ctx["model"]
-    De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation  # per rank (dims: 1/world of the row)
-    Bk = world * ctx["rows_per_rank"] if ctx["dims"] else ctx["rows_per_rank"]  # rows each rank's kernels see
-    roof = None
-    if launches:
-        avg_s = kms / launches / 1e3
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/traffic.json)
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get(prof_kind, {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
-        if prof_kind == "adam":
-            # one launch per parameter tensor; algorithmic bytes = 4 reads + 4 writes (p, m, v, g=0) of the tensor
-            n_el = (N * De + R * Dr) / 2.0  # average over the two launches per step
-            alg = 8 * 4 * n_el
-            ach = alg / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6, "launches": launches,
-                    "note": "dense Adam (+zero_grad) kernel: 8 x 4 B per parameter element, averaged over the ent/rel launches"}
-        else:
-            # The pooled kernels reuse every candidate row from registers / L2 (PMC traffic is ~1/30 of the logical gather
-            # bytes), so HBM does not bound them: the fp32 VALU + the quarter-rate transcendental pipe do.
-            # achieved = ALGORITHMIC flop per launch (every used (row, pool position, dim) pair term evaluated ONCE; flop per
-            # term from the instruction sequence in model_math.h) / mean launch duration, against the 157.3 TFLOP/s fp32
-            # vector peak of MI355X_MICROARCH.md.  The MFMA route of the bilinear models is priced as its three GEMMs.
-            info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
-            pairs = int((info.cnt.to(torch.int32) > 0).sum().item())  # (row, pool position) pairs the batch really uses
-            units = m_.hidden_dim if MODEL == "RotatE" else De       # pair terms per (row, position)
-            bwd = prof_kind != "pool_fwd"
-            # flop / transcendentals per pair term (one complex dim for RotatE, one float otherwise)
-            per_term = {"RotatE": ((6, 1), (15, 1)), "TransE": ((2, 0), (4, 0)), "pRotatE": ((4, 1), (9, 2)),
-                        "ComplEx": ((2, 0), (4, 0)), "DistMult": ((2, 0), (4, 0))}[MODEL][1 if bwd else 0]
-            mfma = MODEL in ("ComplEx", "DistMult")
-            if mfma:  # S = Q.X^T | dQ = G.X | dX = G^T.Q over the whole [B, P] block
-                flop = 2.0 * Bk * (2 * K) * De
-                trans = 0.0
-            else:
-                flop = float(pairs) * units * per_term[0]
-                trans = float(pairs) * units * per_term[1]
-            ach = flop / avg_s / 1e12
-            label = "pool_bwd (single pass: dq and dx from one evaluation of every pair term)" if bwd else "pool_fwd"
-            roof = {"bound": "mfma" if mfma else "valu", "kernel": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "avg_kernel_us": avg_s * 1e6,
-                    "launches": launches, "algorithmic_flop_per_launch": flop,
-                    "note": f"{label}: {pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop"
-                            + (" (MFMA GEMM: 2*B*P*De)" if mfma else "") + "; peak = fp32 vector / matrix rate of MI355X"}
-            if trans:
-                t_rate = trans / avg_s / 1e12
-                roof.update({"transcendental_rate_Tops": t_rate, "transcendental_peak_Tops": TRANS_PEAK_TOPS,
-                             "transcendental_frac": t_rate / TRANS_PEAK_TOPS,
-                             # issue-slot view: packed fp32 ops take 4 cycles per wave for 2 x 64 results, v_rsq / v_sqrt 8 for 64
-                             "issue_frac": (flop / 2.0 / 32.0 + trans / 8.0) / (1024 * 2.4e9) / avg_s})
-            # secondary: SURVEY 8(d)'s logical gather bytes (what the reference formulation would move) -- a REUSE figure, may
-            # exceed the HBM peak; never a roofline fraction
-            roof["logical_gather_GBps"] = (2 if bwd else 1) * Bk * K * De * 4 / avg_s / 1e9
-    out = {
-        "metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
-        else f"scored triples/sec (pos+K neg), {args.config}", "value": value, "unit": "triples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
-        "data": (f"{DATASET} train triples (packaged asset" + ("; SYNTHETIC triples: train.csv absent upstream" if DATASET == "yago310" else "")
-                 + "), random-init tables (torch.manual_seed(42)), synthetic batch order"),
-        "config": {"workload": ("BASELINE configs[2]: " if args.config == "headline" else f"{args.config}: ")
-                               + f"datasets.{DATASET} + models.{MODEL} hidden_dim={HIDDEN}, K={K}, batch {B}/GPU, "
-                               f"Adversarial alpha={ALPHA}, gamma={GAMMA}, dense Adam lr={LR} (row-lazy exact evaluation); "
-                               "step = sampler + pos/neg forward + loss + backward + Adam",
-                   "global_batch": world * ctx["rows_per_rank"], "negatives": K,
-                   "parallelism": ((f"dims{world} (embedding dimension sharded, 1 score all-reduce/step)" if ctx["dims"] else
-                                    f"table-rows{world} (entity table + Adam state sharded by row; pool rows all-reduce, positive rows all-to-all)"
-                                    if ctx["trows"] else f"dp{world} (rows, sparse grad all-reduce)") if world > 1 else "single")},
-        "loss": float(loss.item()),
-        "roofline": roof,
-    }
-    if world == 1 and args.mrr_epochs > 0:
+    ctx = res["ctx"]
+    if world == 1 and args.mrr_epochs > 0 and not ctx["trows"]:
         out["mrr"] = train_and_rank(ctx, args.mrr_epochs, args.warmup + 8 + args.steps)
-    if world == 1 and args.config == "headline" and not args.no_variants:
+    if world == 1 and args.config == "headline" and not args.no_variants and not ctx["trows"]:
         out["step_variants"] = step_variants(ctx)
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(rows=args.cpu_rows)

@@ -231,6 +231,44 @@ int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, fl
                                    int mode, int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
                                    void *stream);
 
+/* ---- row-sharded entity table (several GPUs; the reference is single-process: no counterpart to cite) ----------------
+ * Rank g of `world` owns the entity rows e with e % world == g, at shard index e / world (table, dense gradient and Adam
+ * state alike).  mkb_amd/table_rows.py moves rows between owners and users with these three calls and torch.distributed
+ * (RCCL) collectives; the scoring step itself runs unchanged on a compact table [pool rows | ... | heads | tails].
+ *
+ * mkb_rows_route: group row requests by owner, request order kept inside a group.  sample_layout != 0: ids = sample [n, 3],
+ *   the requests are its n heads followed by its n tails (2n requests); sample_layout == 0: ids = a flat list of n global
+ *   entity ids.  send_ids = shard indices in grouped order (the payload of the id all-to-all), slot = where request j went,
+ *   counts [world] = requests per owner (the all-to-all's split sizes), compact [n, 3] (sample layout only, or null) = the
+ *   triples re-addressed into the compact table: (row0 + slot[j], r, row0 + slot[n + j]).
+ * A row segment lists rows of the shard: world == 0: ids are shard indices; world > 0: ids are GLOBAL entity ids and only
+ *   those this rank owns are touched (gather: the others become zero rows, so that an all-reduce over the ranks completes
+ *   the block; scatter: skipped).  local_ids (gather, optional out [n]): the shard index of each entry, or -1.
+ * mkb_rows_gather: rows[j] = shard[ids[j]] for up to 4 segments in one launch; riders of the same launch: weight_sum[0] =
+ *   sum of weight [n_weight] (fixed-order tree; null = none) and clearing `zero` (zero_bytes, multiple of 16; 0 = none).
+ * mkb_rows_scatter_add: grad[ids[j]] += rows[j] (fp32 atomics: duplicates add); rider: dense_dst [dense_n] += dense_src. */
+typedef struct {
+    const int64_t *ids;
+    int64_t n;
+    float *rows;          /* [n, D] */
+    int32_t world, rank;
+    int64_t *local_ids;   /* gather only; may be null */
+} mkb_row_seg_t;
+int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, int world, int64_t row0, int64_t *send_ids,
+                   int32_t *slot, int64_t *counts, int64_t *compact, void *stream);
+int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
+                    const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes, void *stream);
+int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs, float *dense_dst,
+                         const float *dense_src, int64_t dense_n, void *stream);
+/* mkb_adam_rows_advance (grad != null) / mkb_adam_rows_catchup (grad == null) for a shard of such a table: the rows to visit
+ * are global_ids [n_global] (entries other ranks own are skipped) followed by local_ids [n_local_ids] (shard indices).
+ * Negative entries of any id list of the row-lazy calls are skipped. */
+int mkb_adam_rows_advance_sharded(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
+                                  int64_t n_rows, int64_t D, const int64_t *global_ids, int64_t n_global, int world, int rank,
+                                  const int64_t *local_ids, int64_t n_local_ids, int64_t step_upto, float lr, float beta1,
+                                  float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead,
+                                  void *stream);
+
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the
  * candidate list and filter bias of datasets.base.TestDataset (datasets/base.py:196-241): for each test triple

@@ -41,6 +41,11 @@ class AdamDense(Structure):  # mkb_adam_dense_t: a small dense tensor stepped in
                 ("n", c_int64), ("step", c_int64)]
 
 
+class RowSeg(Structure):  # mkb_row_seg_t: rows of a table shard listed by shard index (world == 0) or global entity id
+    _fields_ = [("ids", c_void_p), ("n", c_int64), ("rows", c_void_p), ("world", c_int32), ("rank", c_int32),
+                ("local_ids", c_void_p)]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -94,6 +99,14 @@ _SIGNATURES = {
                                                c_int64, c_float, c_float, c_float, c_float, POINTER(AdamDense), c_void_p,
                                                c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p]),
+    "mkb_rows_route": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mkb_rows_gather": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                c_int64, c_void_p]),
+    "mkb_rows_scatter_add": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_void_p, c_int64,
+                                     c_void_p]),
+    "mkb_adam_rows_advance_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                              c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_float, c_float,
+                                              c_float, c_float, POINTER(AdamDense), c_void_p, c_void_p]),
     "mkb_check_ids": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "mkb_kl_divergence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),

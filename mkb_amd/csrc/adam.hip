@@ -137,6 +137,10 @@ struct AdamRowArgs {
     int32_t n_rows_listed;  // catch-up kernel: rows to visit (n_ids row blocks of rows_per_block rows each)
     int32_t rows_per_block; // power of two <= 16: kCatchThreads / rows_per_block lanes x (float4 | float2) cover one row
     int32_t vec4;           // rows are read as float4 per lane (D % 4 == 0, 16-byte aligned arrays), else float2 / scalar
+    // row-sharded table (mkb_adam_rows_advance_sharded): the first own_n listed rows are GLOBAL entity ids of a table whose
+    // row e lives on rank e % own_world at index e / own_world; entries another rank owns are skipped.  `ids` follows them.
+    const int64_t *own_ids;
+    int32_t own_n, own_world, own_rank;
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -319,19 +323,24 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
         return;
     }
     __shared__ int s_old2[16];
-    const bool ahead = A.ids || A.seg_pool;  // (a flush walks every row, most of them with nothing pending: no guessing there)
+    const bool ahead = A.ids || A.seg_pool || A.own_ids;  // (a flush walks every row, most of them with nothing pending: no guessing there)
     const int rpb = A.rows_per_block, lanes = kCatchThreads / rpb;
     const int sub = (int)threadIdx.x / lanes, lane = (int)threadIdx.x - sub * lanes;
     const int64_t r = bid * rpb + sub;
-    const bool valid = r < A.n_rows_listed;
+    bool valid = r < A.n_rows_listed;
     int64_t row = 0;
     if (valid) {
-        if (A.ids) row = A.ids[r];
+        if (A.own_ids && r < A.own_n) {
+            const int64_t e = A.own_ids[r];
+            row = (int)(e % A.own_world) == A.own_rank ? e / A.own_world : -1;
+        } else if (A.own_ids) row = A.ids[r - A.own_n];
+        else if (A.ids) row = A.ids[r];
         else if (A.seg_pool) row = r < A.seg_P ? A.seg_pool[r]
                                  : (r < A.seg_P + A.seg_B ? A.seg_sample[3 * (r - A.seg_P)]
                                                           : A.seg_sample[3 * (r - A.seg_P - A.seg_B) + 2]);
         else row = r;
     }
+    if (row < 0) { valid = false; row = 0; }  // a negative id = "not a row of this table" (an entry another rank owns): skipped
     if (A.vec4) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
     else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
 }
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     }
     if (bid == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
     const int64_t row = A.ids[bid];
+    if (row < 0) return;  // (workgroup-uniform) an entry another rank owns in a row-sharded table's id list
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
     float *p = A.p + row * A.D, *g = A.g + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
     if ((A.D & 3) == 0) {  // 16-byte aligned rows: one float4 per lane and array
@@ -429,10 +439,17 @@ static int attach_rider(AdamRowArgs &A, const mkb_adam_dense_t *rider, float lr,
 
 static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                         int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float lr, float beta1,
-                        float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead, void *stream) {
+                        float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead, void *stream,
+                        const int64_t *own_ids = nullptr, int64_t own_n = 0, int own_world = 0, int own_rank = 0) {
     AdamRowArgs A{};
     if (int rc = fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, ids, D, step_upto, lr, beta1, beta2, eps)) return rc;
     int64_t n = ids ? n_ids : n_rows;
+    if (own_ids) {
+        MKB_REQUIRE(own_n > 0 && own_n <= INT32_MAX && own_world >= 1 && own_rank >= 0 && own_rank < own_world, "bad ownership");
+        MKB_REQUIRE(ids || n_ids == 0, "null local id list");
+        A.own_ids = own_ids; A.own_n = (int32_t)own_n; A.own_world = own_world; A.own_rank = own_rank;
+        n = own_n + n_ids;
+    }
     if (n <= 0 || step_upto <= 0) n = 0;  // nothing can be pending before the first step
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
     set_row_blocks(A, n);
@@ -441,7 +458,7 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
     if (n + extra == 0) return MKB_OK;
     size_t lds = 0;
-    if (draw_ahead && ids && sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
+    if (draw_ahead && (ids || own_ids) && sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
     ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
     hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(n + extra + A.first_row_block)), dim3(kCatchThreads), lds,
                        (hipStream_t)stream, A);
@@ -510,6 +527,20 @@ extern "C" int mkb_adam_rows_advance(float *param, float *grad, float *exp_avg, 
     MKB_REQUIRE(grad, "null gradient (use mkb_adam_rows_catchup)");
     return mkb::rows_advance(param, grad, exp_avg, exp_avg_sq, last, consts, n_rows, D, ids, n_ids, step_upto, lr, beta1, beta2,
                              eps, rider, draw_ahead, stream);
+}
+
+// Row-sharded table: the rows to visit are given as GLOBAL entity ids (the candidate pool, the same on every rank: entries
+// another rank owns are skipped) followed by shard indices (the rows other ranks asked this owner for).  grad == null: the
+// plain catch-up (no deferred real step).
+extern "C" int mkb_adam_rows_advance_sharded(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last,
+                                             float *consts, int64_t n_rows, int64_t D, const int64_t *global_ids,
+                                             int64_t n_global, int world, int rank, const int64_t *local_ids,
+                                             int64_t n_local_ids, int64_t step_upto, float lr, float beta1, float beta2,
+                                             float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead, void *stream) {
+    MKB_REQUIRE(global_ids && n_global > 0, "null global id list (use mkb_adam_rows_advance)");
+    MKB_REQUIRE(grad || !rider, "a dense rider needs the advance form (grad != null)");
+    return mkb::rows_advance(param, grad, exp_avg, exp_avg_sq, last, consts, n_rows, D, local_ids, n_local_ids, step_upto,
+                             grad ? lr : 0.f, beta1, beta2, eps, rider, draw_ahead, stream, global_ids, n_global, world, rank);
 }
 
 extern "C" int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last,

@@ -1,0 +1,247 @@
+// Row movement of the ROW-SHARDED entity table (mkb_amd/table_rows.py; BASELINE config 5).
+//
+// The reference is single-process: it has no counterpart to cite.  Rank g of `world` owns the entity rows e with
+// e % world == g at shard index e / world.  A training step of one rank needs
+//   * the batch's candidate pool rows (the same ids on every rank): every owner fills in the rows it holds, an
+//     all-reduce of the (disjoint) block completes it;
+//   * the heads and tails of its own triples, each from its owner: requests grouped by owner (mkb_rows_route), an
+//     all-to-all of the ids, the owners read the rows (mkb_rows_gather), an all-to-all brings them back;
+//   * afterwards the gradient rows go the same ways in reverse and the owners add them (mkb_rows_scatter_add).
+// These kernels are the device side of that: plain HBM row copies, 16 bytes per lane, one workgroup per row, no host
+// round trip (the split sizes of the all-to-alls are read back one batch AHEAD, see table_rows.py).
+#include "common.h"
+
+namespace mkb {
+
+constexpr int kRouteThreads = 1024;
+constexpr int kRowThreads = 256;
+constexpr int kMaxSegs = 4;
+
+// ------------------------------------------------------------------------------------------------ route
+struct RouteArgs {
+    const int64_t *sample;  // [b, 3] (heads then tails are the 2b requests), or a flat id list [n] when flat != 0
+    int b, world, flat, n_flat;
+    int64_t row0;           // compact-table row of the first private row
+    int64_t *send_ids;      // [2b] shard indices, grouped by owner, request order kept inside a group
+    int32_t *slot;          // [2b] position of request j in the grouped order (j < b: head of triple j, else tail of j - b)
+    int64_t *counts;        // [world]
+    int64_t *compact;       // [b, 3] the triples re-addressed into the compact table: (row0 + slot[j], r, row0 + slot[b + j])
+};
+
+// One workgroup: a counting sort by owner done as `world` stable compactions (a few block scans of 1024 flags each; the
+// list is 2b <= a few thousand ids, so this is latency, not bandwidth).
+__global__ __launch_bounds__(kRouteThreads) void rows_route_kernel(RouteArgs A) {
+    __shared__ int s_cnt[kRouteThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = A.flat ? A.n_flat : 2 * A.b;
+    int offset = 0;
+    for (int w = 0; w < A.world; ++w) {
+        const int start = offset;
+        for (int base = 0; base < n; base += kRouteThreads) {
+            const int j = base + tid;
+            int64_t id = 0;
+            bool flag = false;
+            if (j < n) {
+                id = A.flat ? A.sample[j] : (j < A.b ? A.sample[3 * (int64_t)j] : A.sample[3 * (int64_t)(j - A.b) + 2]);
+                flag = (int)(id % A.world) == w;
+            }
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) s_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int v = 0; v < kRouteThreads / 64; ++v) {
+                const int c = s_cnt[v];
+                before += v < wave ? c : 0;
+                total += c;
+            }
+            if (flag) {
+                const int s = offset + before + __popcll(bal & ((1ull << lane) - 1ull));
+                A.send_ids[s] = id / A.world;
+                A.slot[j] = s;
+            }
+            offset += total;
+            __syncthreads();
+        }
+        if (tid == 0) A.counts[w] = offset - start;
+    }
+    __syncthreads();  // slot[] was written by other lanes of this workgroup
+    if (A.compact && !A.flat) {
+        for (int j = tid; j < A.b; j += kRouteThreads) {
+            A.compact[3 * (int64_t)j] = A.row0 + A.slot[j];
+            A.compact[3 * (int64_t)j + 1] = A.sample[3 * (int64_t)j + 1];
+            A.compact[3 * (int64_t)j + 2] = A.row0 + A.slot[A.b + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gather / scatter
+struct RowSeg {
+    const int64_t *ids;
+    float *rows;
+    int64_t *local_ids;
+    int n, world, rank;
+};
+
+struct RowMoveArgs {
+    float *shard;        // gather: the table shard (read); scatter: its dense gradient (atomically added to)
+    int64_t D;
+    RowSeg seg[kMaxSegs];
+    int n_segs, row_blocks;
+    // riders behind the row workgroups
+    const float *weight; int n_weight; float *weight_sum;   // gather: sum of the batch's weights (fixed-order tree)
+    float4 *zero; int64_t zero_vec4;                        // gather: clear a scratch buffer (the compact gradient)
+    float *dense_dst; const float *dense_src; int64_t dense_n;  // scatter: dense_dst += dense_src (the relation gradient)
+    int rider_blocks;
+};
+
+__device__ __forceinline__ bool locate(const RowMoveArgs &A, int block, int &s, int &j) {
+    s = 0;
+    j = block;
+    while (s < A.n_segs && j >= A.seg[s].n) { j -= A.seg[s].n; ++s; }
+    return s < A.n_segs;
+}
+
+// shard row of entry j of a segment, or -1 when another rank owns it
+__device__ __forceinline__ int64_t shard_row(const RowSeg &S, int j) {
+    const int64_t id = S.ids[j];
+    if (S.world <= 0) return id;
+    return (int)(id % S.world) == S.rank ? id / S.world : -1;
+}
+
+__global__ __launch_bounds__(kRowThreads) void rows_gather_kernel(RowMoveArgs A) {
+    const int tid = threadIdx.x;
+    int s, j;
+    if ((int)blockIdx.x >= A.row_blocks) {
+        const int rb = (int)blockIdx.x - A.row_blocks;
+        if (rb == 0 && A.weight_sum) {  // fixed order: strided partials, wave butterfly, the four wave totals left to right
+            __shared__ float red[kRowThreads / 64];
+            float acc = 0.f;
+            for (int i = tid; i < A.n_weight; i += kRowThreads) acc += A.weight[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();
+            if (tid == 0) A.weight_sum[0] = red[0] + red[1] + red[2] + red[3];
+        }
+        for (int64_t e = (int64_t)rb * kRowThreads + tid; e < A.zero_vec4; e += (int64_t)A.rider_blocks * kRowThreads)
+            A.zero[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    if (!locate(A, (int)blockIdx.x, s, j)) return;
+    const RowSeg &S = A.seg[s];
+    const int64_t r = shard_row(S, j);
+    if (tid == 0 && S.local_ids) S.local_ids[j] = r;
+    float *out = S.rows + (int64_t)j * A.D;
+    const float *in = A.shard + (r < 0 ? 0 : r) * A.D;
+    if ((A.D & 3) == 0) {
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        for (int64_t k = tid; k < (A.D >> 2); k += kRowThreads) out4[k] = r < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : in4[k];
+    } else {
+        for (int64_t k = tid; k < A.D; k += kRowThreads) out[k] = r < 0 ? 0.f : in[k];
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void rows_scatter_add_kernel(RowMoveArgs A) {
+    const int tid = threadIdx.x;
+    int s, j;
+    if ((int)blockIdx.x >= A.row_blocks) {
+        const int rb = (int)blockIdx.x - A.row_blocks;
+        for (int64_t e = (int64_t)rb * kRowThreads + tid; e < A.dense_n; e += (int64_t)A.rider_blocks * kRowThreads)
+            A.dense_dst[e] += A.dense_src[e];
+        return;
+    }
+    if (!locate(A, (int)blockIdx.x, s, j)) return;
+    const RowSeg &S = A.seg[s];
+    const int64_t r = shard_row(S, j);
+    if (r < 0) return;
+    const float *in = S.rows + (int64_t)j * A.D;
+    float *g = A.shard + r * A.D;
+    // duplicates (a pool id drawn twice, an entity that is several triples' head) add: one fp32 atomic per element
+    if ((A.D & 3) == 0) {
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        for (int64_t k = tid; k < (A.D >> 2); k += kRowThreads) {
+            const float4 v = in4[k];
+            atomicAdd(g + 4 * k, v.x); atomicAdd(g + 4 * k + 1, v.y); atomicAdd(g + 4 * k + 2, v.z); atomicAdd(g + 4 * k + 3, v.w);
+        }
+    } else {
+        for (int64_t k = tid; k < A.D; k += kRowThreads) atomicAdd(g + k, in[k]);
+    }
+}
+
+static int fill_segs(RowMoveArgs &A, const mkb_row_seg_t *segs, int n_segs, int64_t D, bool need_rows16) {
+    MKB_REQUIRE(n_segs >= 0 && n_segs <= kMaxSegs && (n_segs == 0 || segs), "0..%d row segments", kMaxSegs);
+    int64_t total = 0;
+    for (int s = 0; s < n_segs; ++s) {
+        MKB_REQUIRE(segs[s].n >= 0 && segs[s].n <= INT32_MAX, "bad segment size");
+        MKB_REQUIRE(segs[s].n == 0 || (segs[s].ids && segs[s].rows), "null segment pointer");
+        MKB_REQUIRE(segs[s].world == 0 || (segs[s].world > 0 && segs[s].rank >= 0 && segs[s].rank < segs[s].world), "bad world / rank");
+        MKB_REQUIRE(!need_rows16 || (D & 3) != 0 || (((uintptr_t)segs[s].rows) & 15) == 0, "row buffers must be 16-byte aligned");
+        A.seg[s] = RowSeg{segs[s].ids, segs[s].rows, segs[s].local_ids, (int)segs[s].n, segs[s].world, segs[s].rank};
+        total += segs[s].n;
+    }
+    MKB_REQUIRE(total <= INT32_MAX, "too many rows");
+    A.n_segs = n_segs;
+    A.row_blocks = (int)total;
+    return MKB_OK;
+}
+
+}  // namespace mkb
+
+using namespace mkb;
+
+extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, int world, int64_t row0, int64_t *send_ids,
+                              int32_t *slot, int64_t *counts, int64_t *compact, void *stream) {
+    MKB_REQUIRE(ids && send_ids && slot && counts, "null pointer");
+    MKB_REQUIRE(n > 0 && 2 * n <= INT32_MAX && world >= 1 && world <= 4096, "bad n / world");
+    MKB_REQUIRE(sample_layout || !compact, "the compact triples need the [b, 3] layout");
+    RouteArgs A{ids, sample_layout ? (int)n : 0, world, sample_layout ? 0 : 1, (int)n, row0, send_ids, slot, counts, compact};
+    hipLaunchKernelGGL(rows_route_kernel, dim3(1), dim3(kRouteThreads), 0, (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
+                               const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes,
+                               void *stream) {
+    MKB_REQUIRE(shard && n_local > 0 && D > 0, "bad shard");
+    MKB_REQUIRE((D & 3) != 0 || (((uintptr_t)shard) & 15) == 0, "shard must be 16-byte aligned");
+    MKB_REQUIRE(!weight_sum || (weight && n_weight > 0 && n_weight <= INT32_MAX), "bad weights");
+    MKB_REQUIRE(zero_bytes >= 0 && (zero_bytes & 15) == 0 && (zero_bytes == 0 || (zero && (((uintptr_t)zero) & 15) == 0)),
+                "the buffer to clear must be 16-byte aligned and a multiple of 16 bytes");
+    RowMoveArgs A{};
+    A.shard = const_cast<float *>(shard);
+    A.D = D;
+    if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
+    A.weight = weight; A.n_weight = (int)n_weight; A.weight_sum = weight_sum;
+    A.zero = (float4 *)zero; A.zero_vec4 = zero_bytes >> 4;
+    int64_t rb = (A.zero_vec4 + 4 * kRowThreads - 1) / (4 * kRowThreads);  // ~4 float4 per lane
+    if (rb > 1024) rb = 1024;
+    if (rb < 1 && weight_sum) rb = 1;
+    A.rider_blocks = (int)rb;
+    if (A.row_blocks + A.rider_blocks == 0) return MKB_OK;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)(A.row_blocks + A.rider_blocks)), dim3(kRowThreads), 0,
+                       (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+extern "C" int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
+                                    float *dense_dst, const float *dense_src, int64_t dense_n, void *stream) {
+    MKB_REQUIRE(grad && n_local > 0 && D > 0, "bad gradient shard");
+    MKB_REQUIRE(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "bad dense rider");
+    RowMoveArgs A{};
+    A.shard = grad;
+    A.D = D;
+    if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
+    A.dense_dst = dense_dst; A.dense_src = dense_src; A.dense_n = dense_n;
+    int64_t rb = (dense_n + 4 * kRowThreads - 1) / (4 * kRowThreads);
+    if (rb > 256) rb = 256;
+    A.rider_blocks = (int)rb;
+    if (A.row_blocks + A.rider_blocks == 0) return MKB_OK;
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)(A.row_blocks + A.rider_blocks)), dim3(kRowThreads), 0,
+                       (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     const int npb = A.q_slices, pb = b % npb, rg = b / npb;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = (s * 64 + lane) * KPT;
-    // The block's slots are cut into kChunks = 4 x 16 chunks, 4 per wave: chunk c = lanes l == c % cph (mod cph) of half c / cph
+    // The block's slots are cut into kChunks = 16 chunks, one per wave and phase: chunk c = lanes l == c % cph (mod cph) of half c / cph
     const int cph = kChunks / halves;
     MKB_TRACE_T(tr_t0);
     MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
@@ -730,8 +730,9 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         }
         float extra = 0.f;
         // lanes of chunk c of a half: l0, l0 + cph, ... (bit pattern with every cph-th bit set, shifted by l0)
-        const unsigned long long cm = cph == 8 ? 0x0101010101010101ull : cph == 16 ? 0x0001000100010001ull
-                                      : cph == 32 ? 0x0000000100000001ull : 0x1ull;
+        // (cph = 16 / halves in {16, 8, 4, 2}; all-ones / (2^cph - 1) = 1 at every cph-th bit.  4 and 2 -- four or eight halves,
+        // i.e. more than 128 positions per block -- were missing from an enumerated table here until round 3)
+        const unsigned long long cm = ~0ull / ((1ull << cph) - 1ull);
         // Hand-off between phases.  Wave v owns chunk (4 v + g) mod 64 in (global) phase g; that chunk was wave v + 1's in
         // phase g - 4, wave v + 2's in phase g - 8, ...: wave v may enter phase g as soon as wave v + 1 has finished phase
         // g - 4 (which, by the same rule, implies every earlier owner has).  Four chunks per wave instead of one give the chain

@@ -101,6 +101,26 @@ class Adam:
                                                      self._sampler_handle(p.device), _hip.stream_ptr()),
                            "mkb_adam_rows_catchup")
 
+    def catch_up_sharded(self, p, global_ids, world, rank, local_ids):
+        """``catch_up`` for a ROW SHARD of a table (``mkb_amd.table_rows``): the rows to make current are the entries of
+        ``global_ids`` this rank owns (``e % world == rank``, shard index ``e // world``) plus the shard indices
+        ``local_ids``; one launch, no id list is materialised on the way."""
+        st = self._state(p)
+        upto = st["n"]
+        if upto <= 0:
+            return
+        st["caught_up"] = (None, upto)
+        lib, c = _hip.lib(), self._consts(st, upto)
+        defer = bool(st.get("defer"))
+        n_loc = 0 if local_ids is None else local_ids.numel()
+        with torch.cuda.device(p.device):
+            _hip.check(lib.mkb_adam_rows_advance_sharded(
+                _hip.ptr(p.data), _hip.ptr(st["g"]) if defer else None, _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
+                _hip.ptr(c), p.shape[0], p.shape[1], _hip.ptr(global_ids), global_ids.numel(), world, rank,
+                _hip.ptr(local_ids) if n_loc else None, n_loc, upto, self._lr_of(st, upto), self.betas[0], self.betas[1],
+                self.eps, self._take_dense() if defer else None, self._sampler_handle(p.device), _hip.stream_ptr()),
+                "mkb_adam_rows_advance_sharded")
+
     def catch_up_generate(self, p, sampler_handle, sample, B, mode_id, neg, pool, pos, cnt, touched):
         """``catch_up(p, rows of this batch)`` fused with the sampler's filter + next-pool draw (one launch; see
         ``sampling.NegativeSampling.generate_with_catch_up``)."""

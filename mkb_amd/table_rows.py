@@ -1,30 +1,39 @@
 """Row-sharded entity table across the GPUs of one node (BASELINE config 5: YAGO3-10, 123 k entities, RotatE-500; SURVEY
 8(e) row 3).  The reference has no distributed code; this is the partitioning ``north_star`` names:
 
-* rank g OWNS the entity rows e with ``e % world == g`` (local index ``e // world``): 1/world of the table, of its dense
-  gradient and of the optimizer state.  The relation table (a few rows) is replicated;
-* the global batch is cut by rows (rank g scores rows ``[g*B/world, (g+1)*B/world)``) against ONE candidate pool -- every
-  rank replays the same MT19937 stream, so the negatives are bit-identical to a single-process run;
-* per step, in this order
-    1. pool rows  ``[P, De]``: every owner fills in the rows it holds, ONE all-reduce of the (disjoint) block makes it
-       complete everywhere (an all-gather with uneven ownership; 2 MB at P = 512, De = 1000);
-    2. positive rows: the heads / tails of this rank's triples are requested from their owners -- all-to-all of the id
-       lists, all-to-all of the rows;
-    3. local compute on the COMPACT table ``[pool rows | heads | tails]`` (``P + 2b`` rows) with the ids of the batch
-       remapped into it: the fused HIP step (``mkb_pool_step``) runs unchanged, it never sees the global table;
-    4. pool-row gradients + the relation gradient + the loss share: ONE all-reduce ("RCCL all-reduce of the sparse
-       gradients"); each owner adds the rows it holds into its gradient shard;
-    5. positive-row gradients travel back along the routes of 2 (all-to-all) and are scatter-added by their owners;
-  then every rank steps dense Adam on its own shard: no optimizer communication.
+* rank g OWNS the entity rows e with ``e % world == g`` (shard index ``e // world``): 1/world of the table, of its dense
+  gradient and of the optimizer state (``mkb_amd.optim.Adam(lazy_rows=True)`` steps the shard row-lazily, exactly like the
+  single-GPU path).  The relation table (a few rows) is replicated;
+* the global batch is cut by rows (every rank scores its own triples) against ONE candidate pool -- every rank replays the
+  same MT19937 stream, so the negatives are bit-identical to a single-process run;
+* per step
+    0. (one batch AHEAD) ``mkb_rows_route`` groups the rank's 2b positive-row requests by owner; the per-owner counts are
+       exchanged and read back on a side stream, the id lists follow -- so the all-to-alls of step t have host-known split
+       sizes without the host ever waiting on the compute stream;
+    1. the owners bring the rows about to be read up to date (``mkb_adam_rows_advance_sharded``) and read them
+       (``mkb_rows_gather``: pool rows they hold -- zero rows otherwise -- straight into the compact table, requested rows
+       into the all-to-all's send buffer; the same launch sums the batch's weights and clears the compact gradient);
+    2. ONE all-reduce completes the pool block everywhere (disjoint supports: the sum IS the gather; the weight sum rides in
+       a spare row), ONE all-to-all delivers the positive rows into the compact table ``[pool | spare | heads, tails]``;
+    3. the fused HIP step (``mkb_pool_step``) runs UNCHANGED on the compact table with the triples re-addressed into it;
+    4. ONE all-reduce sums pool-row gradients + relation gradient + loss share ("RCCL all-reduce of the sparse gradients":
+       they live in one contiguous block of the compact gradient), ONE all-to-all returns the positive-row gradients;
+    5. ``mkb_rows_scatter_add`` adds both into the owner's gradient shard (and the relation gradient into ``relation.grad``);
+  the optimizer then steps each shard locally: no optimizer communication.
 
 Messages are a few MB at most and latency-bound; on xGMI's full mesh the direct all-to-all uses all 7 links at once.
-Everything here is device-agnostic torch code: tests/test_parallel_gloo.py runs it on CPU (world 2 and 4, gloo) with the
-oracle as the compute step and checks it against the single-process step.
+
+Backends.  The row movement goes through a small ``ops`` object: ``HipRowOps`` (the product: the three kernels of
+``mkb_amd/csrc/rows.hip``) -- there is no CPU implementation in this package; tests that exercise the protocol on CPU
+(``gloo``, oracle as the compute step) inject their own torch restatement (``tests/row_ops_torch.py``).
 """
+
 import torch
 import torch.distributed as dist
 
-__all__ = ["RowShardedTable", "TableRowShardedStep", "gather_table_rows", "shard_table_rows"]
+from . import _hip, _links
+
+__all__ = ["HipRowOps", "RowShardedTable", "TableRowShardedStep", "gather_table_rows", "shard_table_rows"]
 
 
 def _world(group):
@@ -35,23 +44,70 @@ def _rank(group):
     return dist.get_rank(group) if dist.is_initialized() else 0
 
 
+class HipRowOps:
+    """Row movement on the device (``mkb_rows_route`` / ``mkb_rows_gather`` / ``mkb_rows_scatter_add``).  A segment is
+    ``(ids, rows, world, rank, local_ids_out)``: ``world == 0`` -> ``ids`` are shard indices; ``world > 0`` -> global
+    entity ids, only this rank's entries are touched."""
+
+    @staticmethod
+    def _segs(segs):
+        arr = (_hip.RowSeg * max(1, len(segs)))()
+        for i, (ids, rows, world, rank, local) in enumerate(segs):
+            _hip.require_device(ids, rows)
+            arr[i] = _hip.RowSeg(ids.data_ptr(), ids.numel(), rows.data_ptr(), world, rank, None if local is None else local.data_ptr())
+        return arr
+
+    def route(self, ids, world, row0=0, sample_layout=False):
+        """-> (send_ids, slot int32, counts int64 [world], compact [b, 3] or None)."""
+        _hip.require_device(ids)
+        ids = _hip.contiguous(ids, torch.int64)
+        n = ids.shape[0]
+        m = 2 * n if sample_layout else n
+        dev = ids.device
+        send = torch.empty(m, dtype=torch.int64, device=dev)
+        slot = torch.empty(m, dtype=torch.int32, device=dev)
+        counts = torch.empty(world, dtype=torch.int64, device=dev)
+        compact = torch.empty((n, 3), dtype=torch.int64, device=dev) if sample_layout else None
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().mkb_rows_route(_hip.ptr(ids), n, 1 if sample_layout else 0, world, row0, _hip.ptr(send),
+                                                 _hip.ptr(slot), _hip.ptr(counts), _hip.ptr(compact), _hip.stream_ptr()),
+                       "mkb_rows_route")
+        return send, slot, counts, compact
+
+    def gather(self, shard, segs, weight=None, weight_sum=None, zero=None):
+        _hip.require_device(shard)
+        with torch.cuda.device(shard.device):
+            _hip.check(_hip.lib().mkb_rows_gather(
+                _hip.ptr(shard), shard.shape[0], shard.shape[1], self._segs(segs), len(segs), _hip.ptr(weight),
+                0 if weight is None else weight.numel(), _hip.ptr(weight_sum), _hip.ptr(zero),
+                0 if zero is None else zero.numel() * zero.element_size(), _hip.stream_ptr()), "mkb_rows_gather")
+
+    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None):
+        _hip.require_device(grad)
+        with torch.cuda.device(grad.device):
+            _hip.check(_hip.lib().mkb_rows_scatter_add(
+                _hip.ptr(grad), grad.shape[0], grad.shape[1], self._segs(segs), len(segs), _hip.ptr(dense_dst),
+                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.stream_ptr()), "mkb_rows_scatter_add")
+
+
 class RowShardedTable:
-    """``data`` = the rows this rank owns of a ``[n_rows, dim]`` table: global row e lives on rank ``e % world`` at local
+    """``data`` = the rows this rank owns of a ``[n_rows, dim]`` table: global row e lives on rank ``e % world`` at shard
     index ``e // world``.  ``grad`` is the matching shard of the dense gradient (allocated on first use)."""
 
-    def __init__(self, n_rows, data, group=None):
+    def __init__(self, n_rows, data, group=None, ops=None):
         self.n_rows, self.group = int(n_rows), group
         self.rank, self.world = _rank(group), _world(group)
         self.data = data if isinstance(data, torch.nn.Parameter) else torch.nn.Parameter(data)
+        self.ops = HipRowOps() if ops is None else ops
         want = (self.n_rows - self.rank + self.world - 1) // self.world
         if self.data.shape[0] != want:
             raise ValueError(f"rank {self.rank} owns {want} of {self.n_rows} rows, got a shard of {self.data.shape[0]}")
 
     @classmethod
-    def from_full(cls, full, group=None, device=None):
+    def from_full(cls, full, group=None, device=None, ops=None):
         rank, world = _rank(group), _world(group)
         shard = full.detach()[rank::world].clone()
-        return cls(full.shape[0], shard if device is None else shard.to(device), group)
+        return cls(full.shape[0], shard if device is None else shard.to(device), group, ops)
 
     @property
     def dim(self):
@@ -64,64 +120,119 @@ class RowShardedTable:
 
     # ---- rows every rank needs (the candidate pool: the same ids, in the same order, on every rank)
     def gather_shared(self, ids):
-        out = torch.zeros((ids.numel(), self.dim), dtype=self.data.dtype, device=self.data.device)
-        mine = (ids % self.world) == self.rank
-        out[mine] = self.data.detach()[torch.div(ids[mine], self.world, rounding_mode="floor")]
+        out = torch.empty((ids.numel(), self.dim), dtype=self.data.dtype, device=self.data.device)
+        self.ops.gather(self.data.detach(), [(ids, out, self.world, self.rank, None)])
         if self.world > 1:
             dist.all_reduce(out, group=self.group)  # disjoint supports: the sum IS the gather, exactly
         return out
 
     def scatter_add_shared(self, ids, grad_rows):
         """``grad_rows`` already summed over the ranks: every owner adds the rows it holds (duplicates in ``ids`` add)."""
-        mine = (ids % self.world) == self.rank
-        self._grad().index_add_(0, torch.div(ids[mine], self.world, rounding_mode="floor"), grad_rows[mine])
+        self.ops.scatter_add(self._grad(), [(ids, grad_rows.contiguous(), self.world, self.rank, None)])
 
-    # ---- rows only this rank needs (the heads / tails of its own triples)
+    # ---- rows only this rank needs (the heads / tails of its own triples): the convenience form, which reads the split
+    #      sizes back at once (TableRowShardedStep plans them one batch ahead instead)
     def gather_private(self, ids):
         """-> (rows ``[len(ids), dim]``, route).  ``route`` brings gradients back with ``scatter_add_private``."""
-        world, dev = self.world, ids.device
-        owner = ids % world
-        order = torch.argsort(owner, stable=True)           # requests grouped by owner, original order inside a group
-        send_ids = torch.div(ids[order], world, rounding_mode="floor")
-        send_counts = torch.bincount(owner, minlength=world)
-        if world == 1:
-            rows = self.data.detach()[send_ids]
-            out = torch.empty_like(rows)
-            out[order] = rows
-            return out, (order, send_ids, None, None)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()  # (host sync: the split sizes of the next two collectives)
-        want = torch.empty(sum(rc), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(want, send_ids, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-        reply = self.data.detach()[want]                      # rows the others asked this owner for
-        got = torch.empty((ids.numel(), self.dim), dtype=self.data.dtype, device=dev)
-        dist.all_to_all_single(got, reply, output_split_sizes=sc, input_split_sizes=rc, group=self.group)
-        out = torch.empty_like(got)
-        out[order] = got
-        return out, (order, want, sc, rc)
+        send_ids, slot, counts, _ = self.ops.route(ids, self.world)
+        route = _Route(self, ids.numel(), send_ids, slot, counts, None)
+        route.exchange_counts()
+        route.resolve()
+        got = torch.empty((ids.numel(), self.dim), dtype=self.data.dtype, device=self.data.device)
+        reply = torch.empty((route.want.numel(), self.dim), dtype=self.data.dtype, device=self.data.device)
+        self.ops.gather(self.data.detach(), [(route.want, reply, 0, 0, None)])
+        route.rows_to_requesters(reply, got)
+        return got[slot.long()], route
 
     def scatter_add_private(self, route, grad_rows):
-        order, want, sc, rc = route
-        grouped = grad_rows[order].contiguous()
-        if sc is None:
-            self._grad().index_add_(0, want, grouped)
+        grouped = torch.empty_like(grad_rows)
+        grouped[route.slot.long()] = grad_rows
+        back = torch.empty((route.want.numel(), self.dim), dtype=grad_rows.dtype, device=grad_rows.device)
+        route.rows_to_owners(grouped, back)
+        self.ops.scatter_add(self._grad(), [(route.want, back, 0, 0, None)])
+
+
+class _Route:
+    """Where the positive rows of one batch live.  ``send_ids`` (shard indices, grouped by owner) and ``slot`` come from
+    ``ops.route``; ``exchange_counts`` tells every owner how many rows each rank will ask it for and starts the read-back of
+    both count vectors on a side stream; ``resolve`` (at the step that uses the route) turns them into the host-known split
+    sizes of the all-to-alls and sends the id lists: ``want`` = the shard indices the other ranks ask this owner for."""
+
+    _side = {}
+
+    def __init__(self, table, n, send_ids, slot, counts, compact):
+        self.table, self.n = table, n
+        self.send_ids, self.slot, self.counts, self.compact = send_ids, slot, counts, compact
+        self.sc = self.rc = self.want = None
+        self._host = self._event = None
+
+    def exchange_counts(self):
+        tb = self.table
+        if tb.world == 1:
             return
-        back = torch.empty((want.numel(), self.dim), dtype=grad_rows.dtype, device=grad_rows.device)
-        dist.all_to_all_single(back, grouped, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-        self._grad().index_add_(0, want, back)
+        both = torch.empty(2 * tb.world, dtype=torch.int64, device=self.counts.device)
+        both[: tb.world] = self.counts
+        work = dist.all_to_all_single(both[tb.world:], both[: tb.world], group=tb.group, async_op=True)
+        if both.is_cuda:  # read back beside the compute stream: the host waits for THIS copy only, never for the step's kernels
+            side = self._side.get(both.device)
+            if side is None:
+                side = self._side[both.device] = torch.cuda.Stream(device=both.device)
+            self._host = torch.empty(2 * tb.world, dtype=torch.int64, pin_memory=True)
+            with torch.cuda.stream(side):
+                if work is not None:
+                    work.wait()
+                self._host.copy_(both, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(side)
+            both.record_stream(side)
+        else:
+            if work is not None:
+                work.wait()
+            self._host = both
+
+    def resolve(self):
+        if self.want is not None:
+            return
+        tb = self.table
+        if tb.world == 1:
+            self.sc, self.rc, self.want = [self.n], [self.n], self.send_ids
+            return
+        if self._event is not None:
+            self._event.synchronize()
+        host = self._host.tolist()
+        self.sc, self.rc = host[: tb.world], host[tb.world:]
+        self.want = torch.empty(sum(self.rc), dtype=torch.int64, device=self.send_ids.device)
+        dist.all_to_all_single(self.want, self.send_ids, output_split_sizes=self.rc, input_split_sizes=self.sc, group=tb.group)
+
+    # rows [sum(rc), D] read by this owner -> the requesters' buffers [n, D] (grouped order), and the way back
+    def rows_to_requesters(self, reply, got, async_op=False):
+        if self.table.world == 1:
+            got.copy_(reply)
+            return None
+        return dist.all_to_all_single(got, reply, output_split_sizes=self.sc, input_split_sizes=self.rc, group=self.table.group,
+                                      async_op=async_op)
+
+    def rows_to_owners(self, grouped, back, async_op=False):
+        if self.table.world == 1:
+            back.copy_(grouped)
+            return None
+        return dist.all_to_all_single(back, grouped, output_split_sizes=self.rc, input_split_sizes=self.sc, group=self.table.group,
+                                      async_op=async_op)
 
 
-def shard_table_rows(model, group=None, device=None):
+def shard_table_rows(model, group=None, device=None, ops=None):
     """-> (entity ``RowShardedTable``, replicated relation ``Parameter``) from a full ``mkb_amd`` (or oracle-style) model
     that every rank built identically (same seed)."""
-    table = RowShardedTable.from_full(model.entity_embedding, group, device)
+    table = RowShardedTable.from_full(model.entity_embedding, group, device, ops)
     rel = model.relation_embedding.detach().clone()
     return table, torch.nn.Parameter(rel if device is None else rel.to(device))
 
 
 def gather_table_rows(table):
     """Reassemble the full table from the shards (checkpointing, evaluation, tests)."""
+    opt = _links.owner(table.data)
+    if opt is not None:
+        opt.flush(table.data)  # a row-lazy optimizer may hold steps that have not been applied yet
     if table.world == 1:
         return table.data.detach().clone()
     per = (table.n_rows + table.world - 1) // table.world
@@ -134,92 +245,170 @@ def gather_table_rows(table):
 
 
 class TableRowShardedStep:
-    """``loss = step(sample, weight, negative_sample, mode)`` for this rank's rows of the global batch; fills
-    ``table.data.grad`` (this rank's shard of the dense entity gradient) and ``relation.grad`` (replicated, already
-    summed) and returns the GLOBAL loss.
+    """``loss = step(sample, weight, negative_sample, mode, next_sample=None)`` for this rank's rows of the global batch;
+    fills ``table.data.grad`` (this rank's shard of the dense entity gradient) and ``relation.grad`` (replicated, already
+    summed) and returns the GLOBAL loss.  ``next_sample``: the triples of the NEXT call (or call ``plan(next_sample)``
+    yourself): their routing is prepared while this step runs, so that the next call starts without a host round trip.
 
-    ``compute(ent, rel, sample, weight, pool_info, mode, weight_sum) -> (loss_share, g_ent, g_rel)`` runs the training
-    step on the compact table; the default is the fused HIP step on a working model of ``model_cls``.  ``pool_info``
-    carries ``pos [b, K]`` (slot -> compact row) and ``cnt [b, P]``; compact row p < P is pool position p."""
+    ``compute(ent, rel, sample, weight, pool_info, mode, weight_sum) -> (loss_share, g_ent, g_rel)`` runs the training step
+    on the compact table; the default is the fused HIP step (``mkb_pool_step``) writing straight into the buffers the
+    collectives use.  ``pool_info`` carries ``pos [b, K]`` (slot -> compact row) and ``cnt [b, P]``; compact row p < P is pool
+    position p."""
 
     def __init__(self, table, relation, alpha, model_cls=None, hidden_dim=None, gamma=None, group=None, compute=None,
                  modulus=None):
         self.table, self.relation, self.alpha, self.group = table, relation, float(alpha), group
-        self.world = table.world
+        self.world, self.ops = table.world, table.ops
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
-        self._work = {}
+        self._bufs, self._models, self._plans = {}, {}, {}
         self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
+        if compute is None and self._trains_modulus and modulus is None:
+            raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")
 
-    # -- default compute: the fused pooled step (mkb_pool_step) on a working model that holds the compact table
-    def _working_model(self, n_rows, device):
-        m = self._work.get(n_rows)
+    # ------------------------------------------------------------------ layout of the compact table
+    def _layout(self, P, b):
+        """Compact table rows: [0, P) pool positions | [P, P + X) spare | [P + X, P + X + 2b) positive rows.  The spare rows
+        of the TABLE carry the all-reduced weight sum (row P, element 0); the spare rows of its GRADIENT carry the relation
+        gradient, the loss share and pRotatE's modulus gradient, so that ONE all-reduce of rows [0, P + X) moves them all."""
+        D = self.table.dim
+        extra = self.relation.numel() + 2
+        X = max(1, -(-extra // D))
+        return D, X, P + X, P + X + 2 * b
+
+    def _buffers(self, P, b, dev):
+        key = (P, b, dev)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            D, X, row0, rows = self._layout(P, b)
+            ent = torch.zeros((rows, D), dtype=torch.float32, device=dev)
+            grad = torch.zeros((rows, D), dtype=torch.float32, device=dev)
+            spare = grad[P: row0].view(-1)
+            n_rel = self.relation.numel()
+            bufs = self._bufs[key] = dict(ent=ent, grad=grad, wsum=ent[P, :1], g_rel=spare[:n_rel].view_as(self.relation),
+                                          loss=spare[n_rel: n_rel + 1], g_mod=spare[n_rel + 1: n_rel + 2],
+                                          pool_ids=torch.arange(P, device=dev))
+        return bufs
+
+    # ------------------------------------------------------------------ routing, one batch ahead
+    def plan(self, sample, pool_size=None):
+        """Prepare the routing of ``sample``'s positive rows (a later ``step(sample, ...)`` picks it up).  Needs the pool
+        size of that step (``2 * sampler.size``) to address the compact table; defaults to the last step's."""
+        P = self._last_P if pool_size is None else pool_size
+        sample = sample if sample.is_contiguous() else sample.contiguous()
+        _, _, row0, _ = self._layout(P, sample.shape[0])
+        send_ids, slot, counts, compact = self.ops.route(sample, self.world, row0, sample_layout=True)
+        route = _Route(self.table, 2 * sample.shape[0], send_ids, slot, counts, compact)
+        route.exchange_counts()
+        self._plans = {(sample.data_ptr(), sample.shape[0], P): (route, sample)}  # (keeps `sample` alive: the key stays unique)
+        return route
+
+    def _route_for(self, sample, P):
+        hit = self._plans.pop((sample.data_ptr(), sample.shape[0], P), None)
+        route = hit[0] if hit is not None else self.plan(sample, P)
+        self._plans = {}
+        route.resolve()
+        return route
+
+    # ------------------------------------------------------------------ the compute step on the compact table
+    def _working_model(self, bufs, dev):
+        m = self._models.get(id(bufs))
         if m is None:
-            ents = {i: i for i in range(n_rows)}
-            rels = {i: i for i in range(self.relation.shape[0])}
-            m = self._model_cls(hidden_dim=self._hidden, entities=ents, relations=rels, gamma=self._gamma).to(device)
-            m.relation_embedding = self.relation  # the replicated table itself: its .grad is the relation gradient
+            rows = bufs["ent"].shape[0]
+            ents, rels = {i: i for i in range(rows)}, {i: i for i in range(self.relation.shape[0])}
+            m = self._model_cls(hidden_dim=self._hidden, entities=ents, relations=rels, gamma=self._gamma).to(dev)
+            # its tables ARE the communication buffers / the replicated parameters: nothing is copied per step
+            m.entity_embedding = torch.nn.Parameter(bufs["ent"], requires_grad=False)
+            m.relation_embedding = self.relation
             if self._modulus is not None:
                 m.modulus = self._modulus
-            elif self._trains_modulus:
-                raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")
-            self._work[n_rows] = m
+            self._models[id(bufs)] = m
         return m
 
-    def _fused(self, ent, rel, sample, weight, info, mode, weight_sum):
-        from .fused import FusedTrainStep
-        from .sampling.negative_sampling import PoolInfo
+    def _fused(self, bufs, compact, weight, info, mode, b, P):
+        from .fused import _workspace
 
-        m = self._working_model(ent.shape[0], ent.device)
-        with torch.no_grad():
-            m.entity_embedding.copy_(ent)
-        if m.entity_embedding.grad is not None:
-            m.entity_embedding.grad.zero_()
-        rel_before = None if rel.grad is None else rel.grad.clone()
-        neg = info.pos.long()  # slot -> compact row (only its pool description is used)
-        P = info.cnt.shape[1]
-        neg._mkb_pool = PoolInfo(torch.arange(P, device=ent.device), info.pos, info.cnt, info.size, info.mode_id, sample)
-        step = self._work.setdefault(("step", ent.shape[0]), FusedTrainStep(m, self.alpha))
-        loss = step(sample, weight, neg, mode, weight_sum=weight_sum)
-        g_rel = rel.grad if rel_before is None else rel.grad - rel_before
-        return loss, m.entity_embedding.grad, g_rel.clone()
+        dev = weight.device
+        m = self._working_model(bufs, dev)
+        K = info.size
+        pos = torch.empty((b, 1), dtype=torch.float32, device=dev)
+        S = torch.empty((b, P), dtype=torch.float32, device=dev)
+        ws = _workspace(m, b, K)
+        gr = _hip.Grads(bufs["grad"].data_ptr(), bufs["g_rel"].data_ptr(), bufs["g_mod"].data_ptr() if self._trains_modulus else None)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(compact), _hip.ptr(weight), _hip.ptr(bufs["pool_ids"]),
+                                                _hip.ptr(info.cnt), b, K, _hip.mode_id(mode), self.alpha, _hip.ptr(bufs["wsum"]),
+                                                _hip.ptr(pos), _hip.ptr(S), _hip.ptr(bufs["loss"]), _hip.ptr(ws),
+                                                _hip.stream_ptr()), "mkb_pool_step")
+        self.positive_score, self._S = pos, S
 
-    def __call__(self, sample, weight, negative_sample, mode):
+    def __call__(self, sample, weight, negative_sample, mode, next_sample=None):
         info = negative_sample._mkb_pool
-        tb, dev = self.table, sample.device
+        tb, ops, dev = self.table, self.ops, sample.device
+        sample = sample if sample.is_contiguous() else sample.contiguous()
+        weight = weight if weight.is_contiguous() else weight.contiguous()
         b, P = sample.shape[0], info.pool.numel()
-        pool_rows = tb.gather_shared(info.pool)                                    # 1
-        pos_rows, route = tb.gather_private(torch.cat([sample[:, 0], sample[:, 2]]))  # 2
-        w_sum = weight.sum().reshape(1)
-        if self.world > 1:
-            dist.all_reduce(w_sum, group=self.group)
-        ent = torch.cat([pool_rows, pos_rows])
-        ar = torch.arange(b, device=dev)
-        compact = torch.stack([P + ar, sample[:, 1], P + b + ar], dim=1).contiguous()
+        self._last_P = P
+        D, X, row0, rows = self._layout(P, b)
+        bufs = self._buffers(P, b, dev)
+        ent, grad = bufs["ent"], bufs["grad"]
+        route = self._route_for(sample, P)
+        if next_sample is not None:
+            self.plan(next_sample, P)  # its count exchange and read-back overlap this step's kernels
+        want = route.want
+        R = want.numel()
+        # 1. owners: rows about to be read become current (row-lazy Adam), then are read
+        opt = _links.owner(tb.data)
+        touched = torch.empty(P + R, dtype=torch.int64, device=dev)  # shard indices written this step (-1: not mine)
+        touched[P:] = want
+        if opt is not None:
+            opt.catch_up_sharded(tb.data, info.pool, self.world, self.rank_of_table, want)
+            opt._state(tb.data)["caught_up"] = (touched, opt._state(tb.data)["n"])
+        reply = torch.empty((R, D), dtype=torch.float32, device=dev)
+        ops.gather(tb.data.detach(), [(info.pool, ent[:P], self.world, tb.rank, touched[:P]), (want, reply, 0, 0, None)],
+                   weight=weight, weight_sum=bufs["wsum"], zero=grad)
+        # 2. positive rows to their users, pool block (+ weight sum) completed everywhere
+        w_rows = route.rows_to_requesters(reply, ent[row0:], async_op=True)
+        w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if self.world > 1 else None
+        for w in (w_rows, w_pool):
+            if w is not None:
+                w.wait()
+        # 3. the training step on the compact table
         rel = self.relation
-        run = self.compute or self._fused
+        if rel.grad is None:
+            rel.grad = torch.zeros_like(rel)
         if self.compute is None:
-            if rel.grad is None:
-                rel.grad = torch.zeros_like(rel)
-        mod = self._modulus if (self.compute is None and self._trains_modulus) else None
-        mod_before = None if mod is None or mod.grad is None else mod.grad.clone()
-        loss, g_ent, g_rel = run(ent, rel, compact, weight, info, mode, w_sum)      # 3
-        # 4: pool-row gradients + relation gradient (+ pRotatE's modulus gradient) + loss share in ONE all-reduce
-        parts = [g_ent[:P].reshape(-1), g_rel.reshape(-1)]
-        if mod is not None:
-            g_mod = (mod.grad if mod_before is None else mod.grad - mod_before).reshape(-1).clone()
-            parts.append(g_mod)
-        buf = torch.cat(parts + [loss.reshape(1).to(g_ent.dtype)])
-        if self.world > 1:
-            dist.all_reduce(buf, group=self.group)
-        if mod is not None:  # replicated scalar: replace this rank's share by the sum
-            mod.grad.add_((buf[-2:-1] - g_mod).view_as(mod.grad))
-        n_pool = P * tb.dim
-        tb.scatter_add_shared(info.pool, buf[:n_pool].view(P, tb.dim))
-        g_rel_sum = buf[n_pool: n_pool + rel.numel()].view_as(rel)
-        if self.compute is None:   # the fused step already added this rank's share into rel.grad: replace it by the sum
-            rel.grad.add_(g_rel_sum - g_rel)
+            self._fused(bufs, route.compact, weight, info, mode, b, P)
         else:
-            rel.grad = g_rel_sum.clone() if rel.grad is None else rel.grad + g_rel_sum
-        tb.scatter_add_private(route, g_ent[P:])                                    # 5
-        return buf[-1]
+            loss, g_ent, g_rel = self.compute(ent, rel, route.compact, weight, info, mode, bufs["wsum"])
+            grad.copy_(g_ent)
+            grad[P: row0].zero_()
+            bufs["g_rel"].copy_(g_rel)
+            bufs["loss"].copy_(loss.reshape(1))
+        # 4. pool-row gradients + relation gradient + loss share (+ modulus gradient): one all-reduce; positive-row
+        #    gradients back to their owners
+        back = torch.empty((R, D), dtype=torch.float32, device=dev)
+        w_back = route.rows_to_owners(grad[row0:], back, async_op=True)
+        w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if self.world > 1 else None
+        for w in (w_back, w_sum):
+            if w is not None:
+                w.wait()
+        # 5. owners add what they hold; the relation gradient joins relation.grad in the same launch
+        ops.scatter_add(tb._grad(), [(info.pool, grad[:P], self.world, tb.rank, None), (want, back, 0, 0, None)],
+                        dense_dst=rel.grad, dense_src=bufs["g_rel"])
+        if self._trains_modulus and self.compute is None:
+            mod = self._modulus
+            if mod.grad is None:
+                mod.grad = torch.zeros_like(mod)
+            mod.grad.add_(bufs["g_mod"].view_as(mod.grad))
+        if opt is not None:
+            _links.mark_touched(tb.data, touched)
+        return bufs["loss"].clone().reshape(())
+
+    @property
+    def rank_of_table(self):
+        return self.table.rank
+
+    @property
+    def negative_score(self):
+        raise AttributeError("the row-sharded step keeps pool scores only (self._S [b, P]); gather them with the sampler's pos map")

@@ -23,7 +23,7 @@ def test_bench_two_ranks_on_one_device(parallelism, scaling):
     env = dict(os.environ, MKB_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--config", "wn18rr-rotate", "--parallelism", parallelism, "--scaling", scaling]
+           "--config", "wn18rr-rotate", "--parallelism", parallelism, "--scaling", scaling, "--no-extras"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -32,3 +32,35 @@ def test_bench_two_ranks_on_one_device(parallelism, scaling):
     assert d["config"]["global_batch"] == (2048 if scaling == "weak" else 1024)
     want = {"dims": "dims2", "rows": "dp2", "table-rows": "table-rows2"}[parallelism]
     assert d["config"]["parallelism"].startswith(want), d["config"]["parallelism"]
+
+
+def test_bench_default_partitioning_is_table_rows_and_reports_the_others():
+    """What the driver launches (no --parallelism): the north_star partitioning is the line's value; dims and rows ride in
+    the same line under other_partitionings."""
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MKB_BENCH_ONE_DEVICE="1")
+    env.pop("MKB_BENCH_PARALLELISM", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--config", "wn18rr-rotate"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["parallelism"].startswith("table-rows2") and "partitioning_failures" not in d
+    assert set(d["other_partitionings"]) == {"dims", "rows"} and all(v["value"] > 0 for v in d["other_partitionings"].values())
+
+
+def test_bench_table_rows_code_path_on_one_rank():
+    """--force-parallelism: the row-sharded step at world 1 (no collective): what one rank computes per step."""
+    from conftest import ROOT
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--config", "yago310-rotate", "--parallelism",
+           "table-rows", "--force-parallelism", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["parallelism"].startswith("table-rows1") and d["value"] > 0

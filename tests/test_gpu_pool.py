@@ -265,7 +265,7 @@ def test_config2_full_size_pooled_equals_general():
 @pytest.mark.parametrize("name,hidden,B,K", [
     ("TransE", 500, 2048, 384),    # 768 positions / 4 blocks = 192 per block = 3 halves of 64 (rounded up to 4)
     ("pRotatE", 500, 2048, 384),
-    ("TransE", 200, 2048, 300),    # 600 positions: 5 halves at one block per 8-half accumulator
+    ("TransE", 201, 4096, 300),    # odd rows (one unit per lane, 8-half accumulator): 600 positions / 2 blocks = 5 halves -> 8
 ])
 def test_single_pass_backward_position_blocks_not_a_power_of_two(name, hidden, B, K):
     """Shapes whose position blocks hold 3, 5, 6 or 7 sixty-four-slot halves: the host rounds the halves up to a power of
@@ -429,8 +429,9 @@ def test_dim_sharded_training_equals_single_device(name, hidden, world, table):
     assert out.returncode == 0 and "TP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-@pytest.mark.parametrize("name,hidden,world", [("RotatE", 24, 2), ("TransE", 33, 3), ("ComplEx", 16, 4), ("pRotatE", 20, 2)])
-def test_row_sharded_table_training_equals_single_device(name, hidden, world):
+@pytest.mark.parametrize("name,hidden,world,size", [("RotatE", 24, 2, "small"), ("TransE", 33, 3, "small"), ("ComplEx", 16, 4, "small"),
+                                                    ("pRotatE", 20, 2, "small"), ("RotatE", 40, 2, "big"), ("TransE", 32, 3, "big")])
+def test_row_sharded_table_training_equals_single_device(name, hidden, world, size):
     """BASELINE config 5's partitioning (mkb_amd.table_rows): entity rows, their gradient and their Adam state sharded by
     row over `world` processes (gloo, all on this one GPU), the fused HIP step running on the compact table of each rank.
     Losses and reassembled tables must equal the single-process run (tests/tr_worker.py)."""
@@ -445,7 +446,9 @@ def test_row_sharded_table_training_equals_single_device(name, hidden, world):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "tr_worker.py"), name, str(hidden), "16"]
+           "127.0.0.1", "--master-port", str(port), str(ROOT / "tests" / "tr_worker.py"), name, str(hidden), "16", size]
+    # "big": FB15k-237 -- shards of > 4096 rows, so each shard steps row-lazily with the real step deferred
+    # (mkb_adam_rows_advance_sharded), against the single-process run with the same optimizer settings
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
     assert out.returncode == 0 and "TR_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

@@ -1,0 +1,99 @@
+"""-m gpu: the row-movement kernels of the row-sharded entity table (mkb_amd/csrc/rows.hip through
+mkb_amd.table_rows.HipRowOps) against their torch restatement (tests/row_ops_torch.py), and the sharded form of the
+row-lazy optimizer's catch-up against the plain one on a materialised id list (bit for bit)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("b", [5, 1024, 1500])
+def test_route_groups_requests_by_owner_in_request_order(world, b):
+    from mkb_amd.table_rows import HipRowOps
+    from row_ops_torch import TorchRowOps
+
+    g = torch.Generator().manual_seed(b * 31 + world)
+    sample = torch.stack([torch.randint(100000, (b,), generator=g), torch.randint(37, (b,), generator=g),
+                          torch.randint(100000, (b,), generator=g)], 1)
+    sample[: b // 3, 0] = sample[0, 0]  # a hot entity: one owner gets far more than its share
+    got = HipRowOps().route(sample.cuda(), world, row0=777, sample_layout=True)
+    ref = TorchRowOps().route(sample, world, row0=777, sample_layout=True)
+    for a, r in zip(got, ref):
+        assert torch.equal(a.cpu(), r), (world, b)
+    flat = torch.randint(5000, (2 * b + 1,), generator=g)
+    got = HipRowOps().route(flat.cuda(), world)
+    ref = TorchRowOps().route(flat, world)
+    assert got[3] is None and all(torch.equal(a.cpu(), r) for a, r in zip(got[:3], ref[:3]))
+
+
+@pytest.mark.parametrize("D", [1000, 64, 37])
+def test_gather_and_scatter_add_equal_the_torch_restatement(D):
+    from mkb_amd.table_rows import HipRowOps
+    from row_ops_torch import TorchRowOps
+
+    g = torch.Generator().manual_seed(D)
+    world, rank, n_local = 4, 1, 900
+    shard = torch.randn(n_local, D, generator=g)
+    pool = torch.randint(n_local * world, (512,), generator=g)      # global ids: ~1/4 are this rank's
+    want = torch.randint(n_local, (700,), generator=g)              # shard indices, with duplicates
+    weight = torch.rand(1024, generator=g)
+    outs = {}
+    for tag, ops, dev in (("hip", HipRowOps(), "cuda"), ("ref", TorchRowOps(), "cpu")):
+        a, b = torch.full((512, D), 7.0, device=dev), torch.full((700, D), 7.0, device=dev)
+        loc = torch.full((512,), 99, dtype=torch.int64, device=dev)
+        wsum = torch.zeros(1, device=dev)
+        junk = torch.ones(333 * 4, device=dev)
+        ops.gather(shard.to(dev), [(pool.to(dev), a, world, rank, loc), (want.to(dev), b, 0, 0, None)], weight=weight.to(dev),
+                   weight_sum=wsum, zero=junk)
+        outs[tag] = [t.cpu() for t in (a, b, loc, wsum, junk)]
+    for x, y in zip(outs["hip"][:3], outs["ref"][:3]):
+        assert torch.equal(x, y)
+    np.testing.assert_allclose(outs["hip"][3].numpy(), outs["ref"][3].numpy(), rtol=1e-6)
+    assert not outs["hip"][4].any()
+    # scatter: duplicates add (atomics: compare to fp32 tolerance), rows other ranks own are skipped, the dense rider adds
+    rows_a, rows_b = torch.randn(512, D, generator=g), torch.randn(700, D, generator=g)
+    dd, ds = torch.randn(4000, generator=g), torch.randn(4000, generator=g)
+    res = {}
+    for tag, ops, dev in (("hip", HipRowOps(), "cuda"), ("ref", TorchRowOps(), "cpu")):
+        grad, dst = torch.zeros(n_local, D, device=dev), dd.clone().to(dev)
+        ops.scatter_add(grad, [(pool.to(dev), rows_a.to(dev), world, rank, None), (want.to(dev), rows_b.to(dev), 0, 0, None)],
+                        dense_dst=dst, dense_src=ds.to(dev))
+        res[tag] = (grad.cpu(), dst.cpu())
+    np.testing.assert_allclose(res["hip"][0].numpy(), res["ref"][0].numpy(), rtol=0, atol=1e-5)
+    assert torch.equal(res["hip"][1], res["ref"][1])
+
+
+@pytest.mark.parametrize("defer", [True, False])
+def test_sharded_catch_up_is_the_plain_catch_up_on_the_materialised_list(defer):
+    """mkb_adam_rows_advance_sharded(global ids filtered by ownership | shard indices) == mkb_adam_rows_advance / _catchup on
+    the list [e // world for owned e] + shard indices: the same rows, the same replay -> identical bits."""
+    from mkb_amd import _links, optim
+
+    world, rank, n_local, D = 4, 2, 6000, 96
+    outs = []
+    for sharded in (True, False):
+        g = torch.Generator().manual_seed(1)
+        p = torch.nn.Parameter(torch.randn(n_local, D, generator=g).cuda())
+        p.grad = torch.zeros_like(p)
+        opt = optim.Adam([p], lr=1e-2, lazy_rows=True, defer_step=defer)
+        for it in range(9):
+            pool = torch.randint(n_local * world, (256,), generator=g).cuda()
+            want = torch.randint(n_local, (300,), generator=g).cuda()
+            mine = (pool % world) == rank
+            ids = torch.cat([torch.where(mine, pool // world, torch.full_like(pool, -1)), want])
+            if sharded:
+                opt.catch_up_sharded(p, pool, world, rank, want)
+                opt._state(p)["caught_up"] = (ids, opt._state(p)["n"])
+            else:
+                opt.catch_up(p, ids)   # (negative entries are skipped by the kernels)
+            rows = torch.unique(ids[ids >= 0])
+            p.grad[rows] += torch.randn(rows.numel(), D, generator=g).cuda()
+            _links.mark_touched(p, ids)
+            opt.step()
+            opt.zero_grad()
+        opt.flush()
+        outs.append((p.detach().clone(), opt.state[p]["m"].clone(), opt.state[p]["v"].clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -144,6 +144,7 @@ def _table_rows_case(rank, world):
 
     from mkb_amd.table_rows import RowShardedTable, TableRowShardedStep, gather_table_rows
     from oracle import scoring
+    from row_ops_torch import TorchRowOps
 
     name, N, R, hidden, gamma, alpha = "RotatE", 61, 5, 8, 6.0, 0.5   # 61 rows: uneven shards
     B, K = 6 * world, 7
@@ -165,7 +166,7 @@ def _table_rows_case(rank, world):
         scale = weight.sum() / weight_sum            # global normaliser W (adversarial.py:28-29)
         return r["loss"] * scale, r["g_ent"] * scale, r["g_rel"] * scale
 
-    table = RowShardedTable.from_full(full.ent)
+    table = RowShardedTable.from_full(full.ent, ops=TorchRowOps())  # (CPU: the protocol; the HIP row kernels run in -m gpu)
     rel = torch.nn.Parameter(full.rel.clone())
     step = TableRowShardedStep(table, rel, alpha, compute=oracle_compute)
     ref_ent, ref_rel = full.ent.clone(), full.rel.clone()
@@ -203,10 +204,11 @@ def test_row_sharded_entity_table_equals_single_process(world):
 
 def _private_gather_case(rank, world):
     from mkb_amd.table_rows import RowShardedTable, gather_table_rows
+    from row_ops_torch import TorchRowOps
 
     torch.manual_seed(3)
     full = torch.randn(37, 4)
-    t = RowShardedTable.from_full(full)
+    t = RowShardedTable.from_full(full, ops=TorchRowOps())
     g = torch.Generator().manual_seed(10 + rank)
     ids = torch.randint(37, (5 + 3 * rank,), generator=g)                 # different counts per rank, duplicates
     rows, route = t.gather_private(ids)

@@ -18,12 +18,14 @@ def main():
     from mkb_amd.table_rows import TableRowShardedStep, gather_table_rows, shard_table_rows
 
     name, hidden, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    big = len(sys.argv) > 4 and sys.argv[4] == "big"  # FB15k-237: shards of > 4096 rows step ROW-LAZILY, real step deferred
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    ds = (datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
-    B = 24 * world
+    B = (64 if big else 24) * world
+    adam_kw = dict(lazy_rows=True, defer_step=True) if big else {}
 
     def batches():
         g = torch.Generator().manual_seed(9)
@@ -41,23 +43,26 @@ def main():
             mod = torch.nn.Parameter(full.modulus.detach().clone().cuda()) if name == "pRotatE" else None
             step = TableRowShardedStep(table, rel, 0.5, model_cls=getattr(models, name), hidden_dim=hidden, gamma=6.0,
                                        modulus=mod)
-            opt = optim.Adam([table.data, rel] + ([mod] if mod is not None else []), lr=2e-3)
+            opt = optim.Adam([table.data, rel] + ([mod] if mod is not None else []), lr=2e-3, **adam_kw)
             lo, hi = rank * B // world, (rank + 1) * B // world
-            for s, w, mode in batches():
-                sl = s[lo:hi].contiguous()
+            todo = [(s[lo:hi].contiguous(), w[lo:hi].contiguous(), mode) for s, w, mode in batches()]
+            for i, (sl, wl, mode) in enumerate(todo):
                 neg = ns.generate(sl, mode)  # one pool draw per call on every rank: identical pools, own rows filtered
-                losses.append(step(sl, w[lo:hi].contiguous(), neg, mode).item())
+                nxt = todo[i + 1][0] if i + 1 < len(todo) and i != 2 else None  # routes planned one batch ahead (and once not)
+                losses.append(step(sl, wl, neg, mode, next_sample=nxt).item())
                 opt.step()
                 opt.zero_grad()
+            opt.flush()
             return losses, gather_table_rows(table), rel.detach().clone(), None if mod is None else mod.detach().clone()
         model = full.cuda()
         opt = optim.Adam([model.entity_embedding, model.relation_embedding] + ([model.modulus] if name == "pRotatE" else []),
-                         lr=2e-3)
+                         lr=2e-3, **adam_kw)
         step = FusedTrainStep(model, 0.5)
         for s, w, mode in batches():
             losses.append(step(s, w, ns.generate(s, mode), mode).item())
             opt.step()
             opt.zero_grad()
+        opt.flush()
         return losses, model.entity_embedding.detach(), model.relation_embedding.detach(), \
             (model.modulus.detach() if name == "pRotatE" else None)
 
