@@ -101,9 +101,9 @@ _SIGNATURES = {
                                                c_void_p]),
     "mkb_rows_route": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_gather": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_int64, c_void_p, c_void_p,
-                                c_int64, c_void_p]),
+                                c_int64, c_void_p, c_void_p]),
     "mkb_rows_scatter_add": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_void_p, c_int64,
-                                     c_void_p]),
+                                     c_void_p, c_void_p]),
     "mkb_adam_rows_advance_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                               c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_float, c_float,
                                               c_float, c_float, POINTER(AdamDense), c_void_p, c_void_p]),

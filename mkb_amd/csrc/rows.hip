@@ -90,9 +90,16 @@ struct RowMoveArgs {
     int n_segs, row_blocks;
     // riders behind the row workgroups
     const float *weight; int n_weight; float *weight_sum;   // gather: sum of the batch's weights (fixed-order tree)
-    float4 *zero; int64_t zero_vec4;                        // gather: clear a scratch buffer (the compact gradient)
+    float4 *zero; int64_t zero_vec4; int zero_tail;         // gather: clear a scratch buffer (the compact gradient)
     float *dense_dst; const float *dense_src; int64_t dense_n;  // scatter: dense_dst += dense_src (the relation gradient)
     int rider_blocks;
+    // Exclusive rows.  occ[r] = how often shard row r is listed in this step's segments: counted by the gather launch (one
+    // fire-and-forget atomic per listed row), read AND reset to 0 by the scatter launch of the same segments.  A row listed
+    // once is added by ONE workgroup and by nobody else in that launch -> plain 16-byte read-modify-write instead of one L2
+    // atomic per element (the atomic units retire ~1 element per clock and channel: 2.5 M of them were 45 us of the YAGO3-10
+    // step).  A workgroup of a row listed several times may find the count already reset by a sibling: 0 != 1, atomics,
+    // still correct; a stale count (a scatter that never ran) can only make a row look shared.
+    unsigned *occ;
 };
 
 __device__ __forceinline__ bool locate(const RowMoveArgs &A, int block, int &s, int &j) {
@@ -126,12 +133,14 @@ __global__ __launch_bounds__(kRowThreads) void rows_gather_kernel(RowMoveArgs A)
         }
         for (int64_t e = (int64_t)rb * kRowThreads + tid; e < A.zero_vec4; e += (int64_t)A.rider_blocks * kRowThreads)
             A.zero[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rb == 0 && tid < A.zero_tail) reinterpret_cast<float *>(A.zero + A.zero_vec4)[tid] = 0.f;  // (odd row lengths)
         return;
     }
     if (!locate(A, (int)blockIdx.x, s, j)) return;
     const RowSeg &S = A.seg[s];
     const int64_t r = shard_row(S, j);
     if (tid == 0 && S.local_ids) S.local_ids[j] = r;
+    if (tid == 0 && A.occ && r >= 0) atomicAdd(A.occ + r, 1u);
     float *out = S.rows + (int64_t)j * A.D;
     const float *in = A.shard + (r < 0 ? 0 : r) * A.D;
     if ((A.D & 3) == 0) {
@@ -158,6 +167,30 @@ __global__ __launch_bounds__(kRowThreads) void rows_scatter_add_kernel(RowMoveAr
     if (r < 0) return;
     const float *in = S.rows + (int64_t)j * A.D;
     float *g = A.shard + r * A.D;
+    __shared__ unsigned s_cnt;
+    if (A.occ) {
+        if (tid == 0) {
+            s_cnt = __hip_atomic_load(A.occ + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.occ[r] = 0u;  // ready for the next step's count
+        }
+        __syncthreads();
+    }
+    const bool own = A.occ && s_cnt == 1u;  // listed once in this step: nobody else writes the row in this launch
+    if (own && (A.D & 3) == 0) {
+        const float4 *in4 = reinterpret_cast<const float4 *>(in);
+        float4 *g4 = reinterpret_cast<float4 *>(g);
+        for (int64_t k = tid; k < (A.D >> 2); k += kRowThreads) {
+            const float4 v = in4[k];
+            float4 a = g4[k];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            g4[k] = a;
+        }
+        return;
+    }
+    if (own) {
+        for (int64_t k = tid; k < A.D; k += kRowThreads) g[k] += in[k];
+        return;
+    }
     // duplicates (a pool id drawn twice, an entity that is several triples' head) add: one fp32 atomic per element
     if ((A.D & 3) == 0) {
         const float4 *in4 = reinterpret_cast<const float4 *>(in);
@@ -204,21 +237,22 @@ extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, 
 
 extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
                                const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes,
-                               void *stream) {
+                               uint32_t *occ, void *stream) {
     MKB_REQUIRE(shard && n_local > 0 && D > 0, "bad shard");
     MKB_REQUIRE((D & 3) != 0 || (((uintptr_t)shard) & 15) == 0, "shard must be 16-byte aligned");
     MKB_REQUIRE(!weight_sum || (weight && n_weight > 0 && n_weight <= INT32_MAX), "bad weights");
-    MKB_REQUIRE(zero_bytes >= 0 && (zero_bytes & 15) == 0 && (zero_bytes == 0 || (zero && (((uintptr_t)zero) & 15) == 0)),
-                "the buffer to clear must be 16-byte aligned and a multiple of 16 bytes");
+    MKB_REQUIRE(zero_bytes >= 0 && (zero_bytes & 3) == 0 && (zero_bytes == 0 || (zero && (((uintptr_t)zero) & 15) == 0)),
+                "the buffer to clear must be 16-byte aligned and hold whole floats");
     RowMoveArgs A{};
     A.shard = const_cast<float *>(shard);
     A.D = D;
     if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
     A.weight = weight; A.n_weight = (int)n_weight; A.weight_sum = weight_sum;
-    A.zero = (float4 *)zero; A.zero_vec4 = zero_bytes >> 4;
+    A.occ = occ;
+    A.zero = (float4 *)zero; A.zero_vec4 = zero_bytes >> 4; A.zero_tail = (int)((zero_bytes & 15) >> 2);
     int64_t rb = (A.zero_vec4 + 4 * kRowThreads - 1) / (4 * kRowThreads);  // ~4 float4 per lane
     if (rb > 1024) rb = 1024;
-    if (rb < 1 && weight_sum) rb = 1;
+    if (rb < 1 && (weight_sum || A.zero_tail)) rb = 1;
     A.rider_blocks = (int)rb;
     if (A.row_blocks + A.rider_blocks == 0) return MKB_OK;
     hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)(A.row_blocks + A.rider_blocks)), dim3(kRowThreads), 0,
@@ -228,7 +262,7 @@ extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, c
 }
 
 extern "C" int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
-                                    float *dense_dst, const float *dense_src, int64_t dense_n, void *stream) {
+                                    float *dense_dst, const float *dense_src, int64_t dense_n, uint32_t *occ, void *stream) {
     MKB_REQUIRE(grad && n_local > 0 && D > 0, "bad gradient shard");
     MKB_REQUIRE(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "bad dense rider");
     RowMoveArgs A{};
@@ -236,6 +270,7 @@ extern "C" int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, con
     A.D = D;
     if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
     A.dense_dst = dense_dst; A.dense_src = dense_src; A.dense_n = dense_n;
+    A.occ = occ;
     int64_t rb = (dense_n + 4 * kRowThreads - 1) / (4 * kRowThreads);
     if (rb > 256) rb = 256;
     A.rider_blocks = (int)rb;

@@ -22,7 +22,7 @@ def _workspace(model, B, K, slot=0):
     """Device scratch for the pooled kernels, cached per (device, table shape, B, K, slot); ``slot`` separates the
     micro-batches of one step, whose forward scratch must survive until their backward half runs."""
     dev = model.entity_embedding.device
-    key = (dev, model.name, model.entity_dim, B, K, slot)
+    key = (dev, model.name, model.entity_dim, model.n_entity, model.n_relation, B, K, slot)  # (the size depends on all of them)
     ws = _workspaces.get(key)
     if ws is None:
         n = _hip.lib().mkb_pool_step_workspace_bytes(model._tables(), B, K)

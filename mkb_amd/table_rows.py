@@ -74,20 +74,24 @@ class HipRowOps:
                        "mkb_rows_route")
         return send, slot, counts, compact
 
-    def gather(self, shard, segs, weight=None, weight_sum=None, zero=None):
+    def gather(self, shard, segs, weight=None, weight_sum=None, zero=None, occ=None):
+        """``occ`` ([shard rows] int32, zeroed once): count how often each shard row is listed, for the matching
+        ``scatter_add`` of the same segments (which resets the counts)."""
         _hip.require_device(shard)
         with torch.cuda.device(shard.device):
             _hip.check(_hip.lib().mkb_rows_gather(
                 _hip.ptr(shard), shard.shape[0], shard.shape[1], self._segs(segs), len(segs), _hip.ptr(weight),
                 0 if weight is None else weight.numel(), _hip.ptr(weight_sum), _hip.ptr(zero),
-                0 if zero is None else zero.numel() * zero.element_size(), _hip.stream_ptr()), "mkb_rows_gather")
+                0 if zero is None else zero.numel() * zero.element_size(), _hip.ptr(occ), _hip.stream_ptr()),
+                "mkb_rows_gather")
 
-    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None):
+    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
         _hip.require_device(grad)
         with torch.cuda.device(grad.device):
             _hip.check(_hip.lib().mkb_rows_scatter_add(
                 _hip.ptr(grad), grad.shape[0], grad.shape[1], self._segs(segs), len(segs), _hip.ptr(dense_dst),
-                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.stream_ptr()), "mkb_rows_scatter_add")
+                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(occ), _hip.stream_ptr()),
+                "mkb_rows_scatter_add")
 
 
 class RowShardedTable:
@@ -190,18 +194,24 @@ class _Route:
                 work.wait()
             self._host = both
 
-    def resolve(self):
+    def resolve(self, lead=0):
+        """``lead``: leave that many int64 slots in front of ``want`` inside one buffer (``self.listed``): the step keeps the
+        shard indices of its pool rows there, so that [pool rows | requested rows] is ONE id list without a copy."""
         if self.want is not None:
             return
         tb = self.table
         if tb.world == 1:
-            self.sc, self.rc, self.want = [self.n], [self.n], self.send_ids
+            self.sc, self.rc = [self.n], [self.n]
+            self.listed = torch.empty(lead + self.n, dtype=torch.int64, device=self.send_ids.device)
+            self.want = self.listed[lead:]
+            self.want.copy_(self.send_ids)
             return
         if self._event is not None:
             self._event.synchronize()
         host = self._host.tolist()
         self.sc, self.rc = host[: tb.world], host[tb.world:]
-        self.want = torch.empty(sum(self.rc), dtype=torch.int64, device=self.send_ids.device)
+        self.listed = torch.empty(lead + sum(self.rc), dtype=torch.int64, device=self.send_ids.device)
+        self.want = self.listed[lead:]
         dist.all_to_all_single(self.want, self.send_ids, output_split_sizes=self.rc, input_split_sizes=self.sc, group=tb.group)
 
     # rows [sum(rc), D] read by this owner -> the requesters' buffers [n, D] (grouped order), and the way back
@@ -262,6 +272,7 @@ class TableRowShardedStep:
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
         self._bufs, self._models, self._plans = {}, {}, {}
+        self._occ = None
         self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
         if compute is None and self._trains_modulus and modulus is None:
             raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")
@@ -307,7 +318,7 @@ class TableRowShardedStep:
         hit = self._plans.pop((sample.data_ptr(), sample.shape[0], P), None)
         route = hit[0] if hit is not None else self.plan(sample, P)
         self._plans = {}
-        route.resolve()
+        route.resolve(lead=P)
         return route
 
     # ------------------------------------------------------------------ the compute step on the compact table
@@ -359,14 +370,15 @@ class TableRowShardedStep:
         R = want.numel()
         # 1. owners: rows about to be read become current (row-lazy Adam), then are read
         opt = _links.owner(tb.data)
-        touched = torch.empty(P + R, dtype=torch.int64, device=dev)  # shard indices written this step (-1: not mine)
-        touched[P:] = want
+        touched = route.listed  # [P + R] shard indices written this step: pool rows (-1: not mine; filled in by the gather) | want
+        if self._occ is None or self._occ.device != dev:
+            self._occ = torch.zeros(tb.data.shape[0], dtype=torch.int32, device=dev)
         if opt is not None:
             opt.catch_up_sharded(tb.data, info.pool, self.world, self.rank_of_table, want)
             opt._state(tb.data)["caught_up"] = (touched, opt._state(tb.data)["n"])
         reply = torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.gather(tb.data.detach(), [(info.pool, ent[:P], self.world, tb.rank, touched[:P]), (want, reply, 0, 0, None)],
-                   weight=weight, weight_sum=bufs["wsum"], zero=grad)
+                   weight=weight, weight_sum=bufs["wsum"], zero=grad, occ=self._occ)
         # 2. positive rows to their users, pool block (+ weight sum) completed everywhere
         w_rows = route.rows_to_requesters(reply, ent[row0:], async_op=True)
         w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if self.world > 1 else None
@@ -395,7 +407,7 @@ class TableRowShardedStep:
                 w.wait()
         # 5. owners add what they hold; the relation gradient joins relation.grad in the same launch
         ops.scatter_add(tb._grad(), [(info.pool, grad[:P], self.world, tb.rank, None), (want, back, 0, 0, None)],
-                        dense_dst=rel.grad, dense_src=bufs["g_rel"])
+                        dense_dst=rel.grad, dense_src=bufs["g_rel"], occ=self._occ)
         if self._trains_modulus and self.compute is None:
             mod = self._modulus
             if mod.grad is None:

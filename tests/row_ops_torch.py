@@ -26,7 +26,7 @@ class TorchRowOps:
             return ids, torch.ones_like(ids, dtype=torch.bool)
         return torch.div(ids, world, rounding_mode="floor"), (ids % world) == rank
 
-    def gather(self, shard, segs, weight=None, weight_sum=None, zero=None):
+    def gather(self, shard, segs, weight=None, weight_sum=None, zero=None, occ=None):
         for seg in segs:
             idx, mine = self._rows(seg)
             seg[1].zero_()
@@ -38,7 +38,7 @@ class TorchRowOps:
         if zero is not None:
             zero.zero_()
 
-    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None):
+    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
         for seg in segs:
             idx, mine = self._rows(seg)
             grad.index_add_(0, idx[mine], seg[1][mine])

@@ -44,7 +44,7 @@ def test_gather_and_scatter_add_equal_the_torch_restatement(D):
         a, b = torch.full((512, D), 7.0, device=dev), torch.full((700, D), 7.0, device=dev)
         loc = torch.full((512,), 99, dtype=torch.int64, device=dev)
         wsum = torch.zeros(1, device=dev)
-        junk = torch.ones(333 * 4, device=dev)
+        junk = torch.ones(333 * 4 + 3, device=dev)  # not a multiple of 16 bytes
         ops.gather(shard.to(dev), [(pool.to(dev), a, world, rank, loc), (want.to(dev), b, 0, 0, None)], weight=weight.to(dev),
                    weight_sum=wsum, zero=junk)
         outs[tag] = [t.cpu() for t in (a, b, loc, wsum, junk)]
@@ -63,6 +63,24 @@ def test_gather_and_scatter_add_equal_the_torch_restatement(D):
         res[tag] = (grad.cpu(), dst.cpu())
     np.testing.assert_allclose(res["hip"][0].numpy(), res["ref"][0].numpy(), rtol=0, atol=1e-5)
     assert torch.equal(res["hip"][1], res["ref"][1])
+    # with the occurrence counts of a gather over the same segments: rows listed once are added without atomics, same sums;
+    # the scatter resets the counts, so a second step starts from zero
+    occ = torch.zeros(n_local, dtype=torch.int32, device="cuda")
+    grad = torch.zeros(n_local, D, device="cuda")
+    for pl, wt in [(pool, want), (pool.flip(0), want[:300])]:
+        a, b = torch.empty(pl.numel(), D, device="cuda"), torch.empty(wt.numel(), D, device="cuda")
+        segs = [(pl.cuda(), a, world, rank, None), (wt.cuda(), b, 0, 0, None)]
+        HipRowOps().gather(shard.cuda(), segs, occ=occ)
+        mine = (pl % world) == rank
+        cnt = torch.bincount(torch.cat([pl[mine] // world, wt]), minlength=n_local)
+        assert torch.equal(occ.cpu().long(), cnt)
+        ra, rb = rows_a[: pl.numel()].cuda(), rows_b[: wt.numel()].cuda()
+        HipRowOps().scatter_add(grad, [(pl.cuda(), ra, world, rank, None), (wt.cuda(), rb, 0, 0, None)], occ=occ)
+        assert not occ.any()
+    want_grad = torch.zeros(n_local, D)
+    TorchRowOps().scatter_add(want_grad, [(pool, rows_a, world, rank, None), (want, rows_b, 0, 0, None)])
+    TorchRowOps().scatter_add(want_grad, [(pool.flip(0), rows_a, world, rank, None), (want[:300], rows_b[:300], 0, 0, None)])
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad.numpy(), rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("defer", [True, False])
