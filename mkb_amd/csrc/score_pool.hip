@@ -324,19 +324,6 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // wave reduction is amortised over twice the pair evaluations); the backward kernels gain nothing from it
     L.fkpt = L.kpt; L.fnw = L.nw;
     if (even4 && NU > 512 && NU <= 1024) { L.fkpt = 4; L.fnw = 4; }
-    // long rows: one wave holds whole rows (score_pool_fwd2.h); position slices so that the grid holds >= 2 workgroups per CU
-    L.fwd2 = 0; L.fwd2_slices = 1;
-    if (!use_mfma(tb) && (NU >= 256 && NU <= 1024 && NU % 4 == 0 && De % 4 == 0 && (!cp || d % 4 == 0) && al16)) {
-        static const bool off = getenv("MKB_POOL_FWD2") && getenv("MKB_POOL_FWD2")[0] == '0';  // A/B switch
-        if (!off) {
-            const int rows_wg = 8 * (cp ? 2 : 4);
-            const int groups = (int)((B + rows_wg - 1) / rows_wg);
-            int sl = (512 + groups - 1) / groups;
-            L.fwd2_slices = sl < 1 ? 1 : (sl > 16 ? 16 : sl);
-            if (const char *e = getenv("MKB_POOL_F2SLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd2_slices = v; }
-            L.fwd2 = 1;
-        }
-    }
     const int target = 256 * 16 / L.nw;  // workgroups for ~16 waves per CU
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -538,7 +525,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
     A.S = S;
     if (occ) { A.occ = occ; A.occ_sample = sample; if (occ_counted) *occ_counted = true; }
     ProfScope ps(MKB_PROF_POOL_FWD, st);
-    return launcher_of(tb->model)(L.fwd2 ? 5 : 0, head, L, A, st);
+    return launcher_of(tb->model)(0, head, L, A, st);
 }
 
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,

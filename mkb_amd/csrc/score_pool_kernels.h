@@ -1038,14 +1038,13 @@ struct PoolLaunch {
     int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the five below
     int bkpt;             // its units per lane (1, 2, or 4 for real-valued models with long rows)
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
-    int fwd2, fwd2_slices; // long rows: the whole-row-per-wave forward (score_pool_fwd2.h) and its position slices
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
     int64_t n_entity;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
-typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd, 5 whole-row forward*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd*/, bool head, const PoolLaunch &L, const PoolArgs &A,
                               hipStream_t st);
 int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
 int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
@@ -1102,11 +1101,7 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
 }
 
 template <int MODEL, bool HEAD>
-static int launch_fwd2(const PoolLaunch &L, const PoolArgs &A, hipStream_t st);  // score_pool_fwd2.h
-
-template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
-    if (which == 5) return launch_fwd2<MODEL, HEAD>(L0, A, st);
     if (which == 4) {
         if constexpr (!ModelTraits<MODEL>::cplx_pair)
             if (L0.bkpt == 4) return launch_bwd1<MODEL, HEAD, 4>(L0, A, st);

@@ -69,12 +69,7 @@ def run(kind="bwd_x", step=10):
     t0 = t[:, 0].min()
     us = lambda x: (x - t0) / 100.0
     start, tl, tp, end = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
-    hw, xcc, rows, bid = t[:, 4], t[:, 5] & 0xF, t[:, 6] & 0xFFFF, t[:, 7]
-    if kind == "fwd":  # pool_fwd2 packs wave 0's cycles at the stage barrier (in units of 64) above the position count
-        waitc = (t[:, 6] >> 16) * 64
-        dur = (t[:, 3] - t[:, 1]) * 24.0  # 100 MHz ticks -> ~2.4 GHz shader cycles
-        print(f"fwd2 stage wait (wave 0): mean {waitc.mean():.0f} cycles = {100 * waitc.sum() / max(dur.sum(), 1):.0f} % of the loop time; "
-              f"positions per workgroup mean {rows.mean():.1f} min {rows.min()} max {rows.max()}")
+    hw, xcc, rows, bid = t[:, 4], t[:, 5] & 0xF, t[:, 6], t[:, 7]
     cu = (hw >> 8) & 0xF
     sh = (hw >> 12) & 0x1
     se = (hw >> 13) & 0x7
