@@ -132,7 +132,8 @@ void mkb_sampler_destroy(mkb_sampler_t *s);
  * backward into the dense gradient buffers.  Uses pool/cnt from mkb_sampler_generate.
  *   ws: workspace of mkb_pool_step_workspace_bytes() bytes; pos_score [B] out, pool_score [B,2K] out
  *   (score of row i against pool position p, meaningful where cnt > 0: elsewhere the tile kernels write 0 and the GEMM
- *   route of ComplEx / DistMult the unmasked product), loss [1] out; weight_sum as in
+ *   route of ComplEx / DistMult leaves the unmasked product or, beyond the deepest position the row's tile uses, nothing),
+ *   loss [1] out; weight_sum as in
  *   mkb_adversarial (null = sum of this call's weights).
  */
 int mkb_pool_supported(const mkb_tables_t *tb, int64_t B, int64_t K); /* 1 if the pooled kernels cover this shape */

@@ -80,7 +80,28 @@ struct GemmTail {
     int M, N, nz;
     int64_t ldc, n;
     float c0, c1;
+    // kind 2: rows m >= max(depth[0 .. n_depth)) were not computed (no batch row uses those pool positions): skipped
+    const int *depth;
+    int n_depth;
 };
+
+#ifdef __HIPCC__
+// max of v[lo .. hi) over the workgroup (any size that is a multiple of 64, <= 1024 lanes); every lane gets the result.
+// v[i] = one past the last pool position batch row i uses (written by the row kernels that open a pooled call): the GEMM
+// route of the bilinear models multiplies only the pool positions somebody uses (P' ~ 340 of 512).
+__device__ __forceinline__ int block_max_i32(const int *__restrict__ v, int lo, int hi, int *s_red) {
+    int m = 0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += (int)blockDim.x) m = max(m, v[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    int r = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = max(r, s_red[w]);
+    __syncthreads();
+    return r;
+}
+#endif
 
 // loss.hip: Adversarial forward + gradient seeds.  defer_finish: the caller sums scratch[1 .. B] itself with
 // adversarial_finish_block (mkb_pool_step: inside the row backward kernel, saving a launch).  neg_tail (kind 1): the

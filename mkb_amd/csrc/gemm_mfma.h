@@ -36,7 +36,25 @@ struct GemmArgs {
     int ksplit;             // K is split over gridDim.z; STORE epilogues then write partial z at C + z * M * ldc
     int64_t lda, ldb, ldc;
     float c0, c1;           // GEMM_STORE_AFFINE: C = c0 + c1 * acc
+    // Used pool depth (optional).  depth[i] = one past the last pool position batch row i uses; positions beyond the deepest
+    // one any relevant row uses carry no information (scores nobody reads, gradient seeds that are exactly 0):
+    //   depth_mode 1: N runs over pool positions, M over batch rows: column tiles beyond the row tile's depth are not computed
+    //   depth_mode 2: K runs over pool positions, M over batch rows: the K range is cut at the row tile's depth
+    //   depth_mode 3: M runs over pool positions: row tiles beyond the depth of ALL n_depth batch rows are not computed
+    const int *depth;
+    int depth_mode, n_depth;
 };
+
+// -> (skip this workgroup, k limit)
+__device__ __forceinline__ bool gemm_depth_cut(const GemmArgs &G, int m0, int tm, int n0, int *s_red, int &k_cut) {
+    k_cut = 0x7fffffff;
+    if (!G.depth) return false;
+    if (G.depth_mode == 3) return m0 >= block_max_i32(G.depth, 0, G.n_depth, s_red);
+    const int lim = block_max_i32(G.depth, m0, min(m0 + tm, G.M), s_red);
+    if (G.depth_mode == 1) return n0 >= lim;
+    k_cut = (lim + 3) & ~3;
+    return false;
+}
 
 // A_MK: A(m,k) = A[m*lda + k]   (k contiguous)      else A_KM: A(m,k) = A[k*lda + m]   (m contiguous)
 // B_NK: B(k,n) = B[idx(n)*ldb + k] (k contiguous)   else B_KN: B(k,n) = B[idx(k)*ldb + n] (n contiguous)
@@ -53,7 +71,10 @@ __global__ __launch_bounds__(TM * 4) void gemm_f32_mfma_kernel(GemmArgs G) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ra[NA], rb[NB];
     const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;  // K range of this split, chunk aligned
-    const int k_lo = blockIdx.z * kper_, k_hi = min(G.K, k_lo + kper_);
+    __shared__ int s_red[16];
+    int k_cut;
+    if (gemm_depth_cut(G, m0, TM, n0, s_red, k_cut)) return;  // (workgroup-uniform)
+    const int k_lo = blockIdx.z * kper_, k_hi = min(min(G.K, k_cut), k_lo + kper_);
 
     // lanes run along the contiguous index of each operand (coalesced); e = element number within the lane's share
     auto a_coord = [&](int e, int &r, int &kk) {
@@ -164,7 +185,10 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;
-    const int k_lo = blockIdx.z * kper_, k_hi = min(G.K, k_lo + kper_);
+    __shared__ int s_red[16];
+    int k_cut;
+    if (gemm_depth_cut(G, m0, TM, n0, s_red, k_cut)) return;  // (workgroup-uniform) a tile nobody needs: not even written
+    const int k_lo = blockIdx.z * kper_, k_hi = min(min(G.K, k_cut), k_lo + kper_);
 
     // element e of this lane's share: (row r, first k kk) for k-contiguous operands (float4 along k),
     //                                  (first row r, k kk) for row-contiguous operands (float4 along m / n)
@@ -298,7 +322,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 // out[c_idx[m]][n] += sum_z part[z][m][n]: the scattered product goes through split-K partials and ONE atomic per element
 // (pool ids may repeat and the positive triples' rows share gradient rows) instead of one atomic per element and K split.
 __device__ __forceinline__ void splitk_scatter_block(const float *__restrict__ part, float *__restrict__ out,
-                                                     const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz, int m) {
+                                                     const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz, int m,
+                                                     const int *__restrict__ depth = nullptr, int n_depth = 0, int *s_red = nullptr) {
+    if (depth && m >= block_max_i32(depth, 0, n_depth, s_red)) return;  // a pool position nobody uses: its partials were skipped
     float *row = out + c_idx[m] * ldc;
     for (int n = threadIdx.x * 4; n < N; n += 1024) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -314,8 +340,10 @@ __device__ __forceinline__ void splitk_scatter_block(const float *__restrict__ p
 }
 
 __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__restrict__ part, float *__restrict__ out,
-                                                             const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz) {
-    splitk_scatter_block(part, out, c_idx, M, N, ldc, nz, (int)blockIdx.x);
+                                                             const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz,
+                                                             const int *__restrict__ depth, int n_depth) {
+    __shared__ int s_red[16];
+    splitk_scatter_block(part, out, c_idx, M, N, ldc, nz, (int)blockIdx.x, depth, n_depth, s_red);
 }
 
 // These products are small (1-2 GFLOP) and short in one dimension: fill the chip by halving the tile height and / or
@@ -348,9 +376,10 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
                 P2.C = partials; P2.ldc = G.N;
                 if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 64>), grid, dim3(256), lds, st, P2);
                 else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 128>), grid, dim3(256), lds, st, P2);
-                if (tail) *tail = GemmTail{2, partials, final_c, G.c_idx, G.M, G.N, ks, G.ldc, 0, 0.f, 1.f};
+                const int *dp = G.depth_mode == 3 ? G.depth : nullptr;
+                if (tail) *tail = GemmTail{2, partials, final_c, G.c_idx, G.M, G.N, ks, G.ldc, 0, 0.f, 1.f, dp, G.n_depth};
                 else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M,
-                                        G.N, G.ldc, ks);
+                                        G.N, G.ldc, ks, dp, G.n_depth);
                 MKB_LAUNCH_CHECK();
                 return MKB_OK;
             }
@@ -360,7 +389,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
-                if (tail) *tail = GemmTail{1, partials, final_c, nullptr, G.M, G.N, ks, G.ldc, n, c0, c1};
+                if (tail) *tail = GemmTail{1, partials, final_c, nullptr, G.M, G.N, ks, G.ldc, n, c0, c1, nullptr, 0};
                 else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
             }
             MKB_LAUNCH_CHECK();

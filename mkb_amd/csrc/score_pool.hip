@@ -17,12 +17,30 @@ struct RowArgs {
     int64_t De, Dr;
     int d, B, nslices;
     float kd;
+    // GEMM route: depth[i] = one past the last pool position row i uses (cnt [B, P]); null = not wanted
+    const uint16_t *cnt;
+    int *depth;
+    int P;
 };
+
+// depth[i] for the GEMM route's "used pool depth" cuts (gemm_mfma.h): one workgroup per row scans the row's multiplicities
+__device__ __forceinline__ void row_depth_256(const uint16_t *__restrict__ cnt, int P, int64_t i, int *__restrict__ depth) {
+    __shared__ int s_dep[4];
+    int m = 0;
+    for (int p = threadIdx.x; p < P; p += 256)
+        if (cnt[i * P + p]) m = p + 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_dep[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) depth[i] = max(max(s_dep[0], s_dep[1]), max(s_dep[2], s_dep[3]));
+}
 
 // Q[i] = query of row i (same math as the LDS staging of the general forward kernel, written to global)
 template <int MODEL, bool HEAD>
 __global__ __launch_bounds__(256) void query_build_kernel(RowArgs A) {
     const int64_t i = blockIdx.x;
+    if (A.depth) row_depth_256(A.cnt, A.P, i, A.depth);
     const int64_t h = A.sample[3 * i], r = A.sample[3 * i + 1], t = A.sample[3 * i + 2];
     const float *eh = A.ent + h * A.De, *er = A.rel + r * A.Dr, *et = A.ent + t * A.De;
     float *q = A.Q + i * A.De;
@@ -111,6 +129,10 @@ struct RowStepArgs {
     int *occ;
     const int64_t *pool;
     int P;
+    // GEMM route: depth[i] = one past the last pool position row i uses, written by row_fwd (see RowArgs::depth)
+    const uint16_t *cnt;
+    int *depth;
+    int depth_P;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -151,6 +173,7 @@ __global__ __launch_bounds__(256) void row_fwd_kernel(RowStepArgs A) {
     }
     acc = block_sum_256_row(acc, red);
     if (threadIdx.x == 0) A.pos_score[i] = finish_score<MODEL>(acc, A.gamma, MODEL == MKB_PROTATE ? A.modulus[0] : 0.f);
+    if (A.depth) row_depth_256(A.cnt, A.depth_P, i, A.depth);
     // housekeeping for the later kernels of the step, behind the row's own work (fire-and-forget stores)
     if (A.occ && threadIdx.x == 64) {  // (counted by the pooled forward / the loss kernel, read by the row backward)
         A.occ[h] = 0; A.occ[t] = 0;
@@ -172,7 +195,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     }
     const int sc_blocks = A.sc.kind == 2 ? A.sc.M : 0;
     if ((int)blockIdx.x < A.dx.blocks + sc_blocks) {
-        splitk_scatter_block(A.sc.part, A.sc.out, A.sc.c_idx, A.sc.M, A.sc.N, A.sc.ldc, A.sc.nz, (int)blockIdx.x - A.dx.blocks);
+        __shared__ int s_red[16];
+        splitk_scatter_block(A.sc.part, A.sc.out, A.sc.c_idx, A.sc.M, A.sc.N, A.sc.ldc, A.sc.nz, (int)blockIdx.x - A.dx.blocks,
+                             A.sc.depth, A.sc.n_depth, s_red);
         return;
     }
     const int64_t i = (int64_t)blockIdx.x - A.dx.blocks - sc_blocks;
@@ -265,6 +290,7 @@ struct Workspace {
     unsigned long long *xused;
     float *rel_rep;
     int *occ;
+    int *depth;  // [B] used pool depth per row (GEMM route)
     size_t bytes;
 };
 
@@ -407,6 +433,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.xused = (unsigned long long *)take(L.bwd1 ? (size_t)L.row_groups * L.q_slices * 8 * 8 : 0);
     w.rel_rep = take(L.rel_copies > 1 ? (size_t)L.rel_copies * L.rel_elems * 4 : 0);
     w.occ = (int *)take((size_t)L.n_entity * 4);
+    w.depth = (int *)take(L.mfma ? (size_t)B * 4 : 0);
     w.bytes = off;
     return w;
 }
@@ -509,15 +536,19 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
                       bool build_queries = true, GemmTail *s_tail = nullptr, int *occ = nullptr, bool *occ_counted = nullptr) {
     if (s_tail) s_tail->kind = 0;
     if (occ_counted) *occ_counted = false;
+    static const bool no_cut = getenv("MKB_GEMM_NO_DEPTH") != nullptr;  // A/B: multiply all P pool positions
+    const bool cut = use_mfma(tb) && !no_cut;
     if (build_queries) {
         RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B,
                    1, tb->phase_div};
+        if (cut) { ra.cnt = cnt; ra.depth = w.depth; ra.P = (int)P; }
         if (int rc = dispatch_query_build(tb, head, ra, B, st)) return rc;
     }
-    if (use_mfma(tb)) {  // S = Q . ent[pool]^T on the matrix cores; every entry is written (cnt masks later)
+    if (use_mfma(tb)) {  // S = Q . ent[pool]^T on the matrix cores, over the pool positions the row tile uses (cnt masks later)
         GemmArgs g{};
         g.A = w.Q; g.lda = tb->entity_dim; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
         g.C = S; g.ldc = P; g.M = (int)B; g.N = (int)P; g.K = (int)tb->entity_dim; g.c0 = 0.f; g.c1 = 1.f;
+        if (cut) { g.depth = w.depth; g.depth_mode = 1; g.n_depth = (int)B; }
         ProfScope ps(MKB_PROF_POOL_FWD, st);
         return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part, s_tail);
     }
@@ -532,11 +563,14 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
                       const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
                       bool chain_queries = true, DxReduce *dx_out = nullptr, GemmTail *x_tail = nullptr) {
     if (x_tail) x_tail->kind = 0;
+    static const bool no_cut = getenv("MKB_GEMM_NO_DEPTH") != nullptr;
+    const bool cut = use_mfma(tb) && !no_cut;  // w.depth was written by this call's row_fwd / query_build
     if (use_mfma(tb)) {
         {   // dQ [B, De] = G [B, P] . ent[pool]
             GemmArgs g{};
             g.A = w.G; g.lda = P; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
             g.C = w.dQ; g.ldc = tb->entity_dim; g.M = (int)B; g.N = (int)tb->entity_dim; g.K = (int)P;
+            if (cut) { g.depth = w.depth; g.depth_mode = 2; g.n_depth = (int)B; }  // (G is exactly 0 beyond a row's depth)
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
             if (int rc = launch_gemm<true, false, GEMM_STORE>(g, st, w.gemm_part)) return rc;
         }
@@ -544,6 +578,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             GemmArgs g{};
             g.A = w.G; g.lda = P; g.B = w.Q; g.ldb = tb->entity_dim; g.b_idx = nullptr;
             g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
+            if (cut) { g.depth = w.depth; g.depth_mode = 3; g.n_depth = (int)B; }
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
             if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part, x_tail)) return rc;
         }
@@ -626,6 +661,7 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
     // rebuild the queries (the forward's copy may have been overwritten by another call sharing the workspace)
     RowArgs ra{tb->ent, tb->rel, sample, w.Q, nullptr, nullptr, tb->entity_dim, tb->relation_dim, tb->hidden_dim, (int)B, 1,
                tb->phase_div};
+    if (use_mfma(tb)) { ra.cnt = cnt; ra.depth = w.depth; ra.P = (int)(2 * K); }  // used pool depth per row (GEMM cuts)
     if (int rc = dispatch_query_build(tb, mode_is_head(mode), ra, B, st)) return rc;
     // G = caller's gradient with the entries no row uses forced to 0 (the single-pass backward reads the mask off G)
     hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((B * 2 * K + 255) / 256)), dim3(256), 0, st, dpool_score, cnt, w.G,
@@ -652,6 +688,8 @@ static int pool_step_fwd(const mkb_tables_t *tb, const int64_t *sample, const in
     static const bool no_own = getenv("MKB_POOL_NO_OWN") != nullptr;  // A/B: every gradient row through atomics
     if (!no_own) { ra.occ = w.occ; ra.pool = pool; ra.P = (int)P; }
     if (L.rel_copies > 1) { ra.rel_rep = w.rel_rep; ra.rel_copies = L.rel_copies; ra.n_rel = (int)tb->n_relation; }
+    static const bool no_cut = getenv("MKB_GEMM_NO_DEPTH") != nullptr;
+    if (use_mfma(tb) && !no_cut) { ra.cnt = cnt; ra.depth = w.depth; ra.depth_P = (int)P; }  // used pool depth per row (GEMM cuts)
     // positive pass (mode None: tail-style formula against the true tail, pipeline.py:211) + negative-path queries
     {
         ProfScope ps(MKB_PROF_GENERAL_FWD, st);

@@ -8,7 +8,7 @@ R=$(pwd)
 O=$R/gpurun_out/refresh
 rm -rf $O; mkdir -p $O   # (everything below is regenerated)
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --mrr-epochs 0 --no-variants"
+BENCH="python $R/bench.py --no-cpu-baseline --mrr-epochs 0 --no-variants --no-traffic"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/ktrace -o run -- $BENCH --steps 60 --warmup 10 > $O/bench_under_rocprof.json 2> $O/ktrace.log
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o run -- $BENCH --steps 20 --warmup 5 --profile-kernel none > $O/pmc_$c.json 2> $O/pmc_$c.log
@@ -16,19 +16,32 @@ done
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU -d $O/pmc_sq -o run -- $BENCH --steps 20 --warmup 5 --profile-kernel none > $O/pmc_sq.json 2> $O/pmc_sq.log
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_clk -o run -- $BENCH --steps 20 --warmup 5 --profile-kernel none > $O/pmc_clk.json 2> $O/pmc_clk.log
 cd $R
-python tools/prof_summary.py $(ls $O/ktrace/*.db | head -1) > $O/kernel_trace_stats.txt
-python tools/prof_summary.py $(ls $O/ktrace/*.db | head -1) timeline > $O/kernel_timeline.txt
+python tools/prof_summary.py $(find $O/ktrace -name "*.db" | head -1) > $O/kernel_trace_stats.txt
+python tools/prof_summary.py $(find $O/ktrace -name "*.db" | head -1) timeline > $O/kernel_timeline.txt
 cp $(ls $O/ktrace/*kernel_stats.csv 2>/dev/null | head -1) $O/rocprofv3_kernel_stats.csv 2>/dev/null
-python tools/pmc_summary.py $(ls $O/pmc_FETCH_SIZE/*.db | head -1) $(ls $O/pmc_WRITE_SIZE/*.db | head -1) > $O/pmc_hbm_traffic.txt
-python tools/pmc_summary.py $(ls $O/pmc_sq/*.db | head -1) $(ls $O/pmc_clk/*.db | head -1) > $O/pmc_sq.txt 2>&1
+python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) > $O/pmc_hbm_traffic.txt
+python tools/pmc_summary.py $(find $O/pmc_sq -name "*.db" | head -1) $(find $O/pmc_clk -name "*.db" | head -1) > $O/pmc_sq.txt 2>&1
 timeout 900 python bench.py --breakdown > $O/bench_default.json 2> $O/bench_default.err
 for c in wn18rr-rotate fb15k237-complex fb15k237-transe fb15k237-distmult yago310-rotate umls-transe; do
-  timeout 300 python bench.py --config $c --no-cpu-baseline --mrr-epochs 0 2>/dev/null | tail -1 >> $O/bench_configs.jsonl
+  timeout 300 python bench.py --config $c --no-cpu-baseline --mrr-epochs 0 --no-traffic 2>/dev/null | tail -1 >> $O/bench_configs.jsonl
 done
-for par in table-rows dims rows; do
-  echo "== world 2 on ONE device (gloo; functional check of the N > 1 code path, not a scaling number): $par" >> $O/one_device_world2.txt
-  MKB_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 10 --warmup 3 --config yago310-rotate --parallelism $par 2>/dev/null | tail -1 >> $O/one_device_world2.txt
+# N > 1 entry path on ONE device (gloo through the host: a functional check, not a scaling number): what the driver launches
+# (default partitioning table-rows, the others + config 5 in the same line), and config 5 on its own
+echo "== python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 (MKB_BENCH_ONE_DEVICE=1, gloo)" >> $O/one_device_world2.txt
+MKB_BENCH_ONE_DEVICE=1 MKB_BENCH_EXTRAS_TIMEOUT=600 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O/one_device_world2.txt
+echo "== ... --config yago310-rotate --no-extras" >> $O/one_device_world2.txt
+MKB_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 2 --steps 20 --warmup 5 --config yago310-rotate --no-extras 2>/dev/null | tail -1 >> $O/one_device_world2.txt
+# what ONE rank of the row-sharded step computes (world 1: every collective degenerates to a copy), next to the plain
+# single-GPU step of the same config, and its kernel trace
+for extra in "" "--parallelism table-rows --force-parallelism"; do
+  timeout 300 python bench.py --config yago310-rotate --no-traffic $extra 2>/dev/null | tail -1 >> $O/table_rows_one_rank.jsonl
 done
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt_tr -o run -- python $R/bench.py --config yago310-rotate --parallelism table-rows --force-parallelism --no-traffic --steps 60 --warmup 10 > /dev/null 2> $O/kt_tr.log
+cd $R
+python tools/prof_summary.py $(find $O/kt_tr -name "*.db" | head -1) > $O/table_rows_one_rank_kernel_stats.txt
+python tools/prof_summary.py $(find $O/kt_tr -name "*.db" | head -1) timeline > $O/table_rows_one_rank_timeline.txt
+rm -rf $O/kt_tr
 timeout 300 python tools/general_path_speed.py > $O/general_path.txt 2>&1
 for w in 1 2 4 8; do timeout 300 python tools/shard_emulate.py $w 2>&1 | grep -v amdgpu.ids >> $O/shard_emulate.txt; done
 timeout 300 python tools/pipeline_speed.py 2>&1 | tail -1 > $O/pipeline_speed.txt
