@@ -72,6 +72,8 @@ __host__ __device__ inline int64_t seed_index(const SeedLayout &L, int64_t i, in
 // The tail of a split-K GEMM that its caller folds into the NEXT launch instead of launching it (gemm_mfma.h):
 //   kind 1: out[i] = c0 + c1 * sum_z part[z * n + i]                       (fixed order; consumed by the loss rows)
 //   kind 2: out[c_idx[m]][col] += sum_z part[(z * M + m) * N + col]        (one atomic per element; rides the row backward)
+//   kind 3: out[m][col] = c0 + c1 * sum_z part[(z * M + m) * N + col] for col < N only, rows of `out` are ldc long (the dense
+//           prefix of the forward tile, score_pool_tile.h; consumed by the loss rows, which mask unused pairs to 0)
 struct GemmTail {
     int kind;  // 0: nothing pending
     const float *part;

@@ -89,7 +89,28 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
     const bool in_regs = K <= 64 * kRowRegs;
     float v[kRowRegs], c[kRowRegs];
-    if (in_regs && NT.kind != 1) {  // (one straight run of loads: a branch inside this loop serialises their latencies)
+    if (in_regs && NT.kind == 3) {  // dense prefix of the scores still in the forward tile's dim-split partials [z][B][N]
+#pragma unroll
+        for (int t = 0; t < kRowRegs; ++t) {
+            const int j = lane + 64 * t;
+            const bool ok = j < K;
+            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
+            if (ok && j < NT.N) {
+                // <= 16 splits: all their loads issued together (a run-time trip count made them one round trip each)
+                const float *pp = NT.part + (int64_t)i * NT.N + j;
+                float pz[16];
+#pragma unroll
+                for (int z = 0; z < 16; ++z) pz[z] = pp[(int64_t)min(z, NT.nz - 1) * NT.n];
+                float acc = 0.f;
+#pragma unroll
+                for (int z = 0; z < 16; ++z) acc += z < NT.nz ? pz[z] : 0.f;  // fixed order: deterministic
+                v[t] = c[t] > 0.f ? NT.c0 + NT.c1 * acc : 0.f;  // (pairs the row does not use were computed: defined as 0)
+                NT.out[(int64_t)i * K + j] = v[t];
+            } else {
+                v[t] = ok ? nrow[j] : 0.f;  // the fringe: finished scores
+            }
+        }
+    } else if (in_regs && NT.kind != 1) {  // (one straight run of loads: a branch inside this loop serialises their latencies)
 #pragma unroll
         for (int t = 0; t < kRowRegs; ++t) {
             const int j = lane + 64 * t;
@@ -213,7 +234,7 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
                        int *occ, const int64_t *occ_sample, const int64_t *occ_pool) {
     float *scal = scratch, *rowpart = scratch + 1;
     GemmTail nt{};
-    if (neg_tail && neg_tail->kind == 1) {
+    if (neg_tail && (neg_tail->kind == 1 || neg_tail->kind == 3)) {
         if (K > 64 * kRowRegs) return set_error(MKB_ERR_INVALID, "split-K scores can only ride rows of <= %d columns", 64 * kRowRegs);
         nt = *neg_tail;
     }

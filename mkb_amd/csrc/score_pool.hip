@@ -291,6 +291,7 @@ struct Workspace {
     float *rel_rep;
     int *occ;
     int *depth;  // [B] used pool depth per row (GEMM route)
+    float *tile_part;
     size_t bytes;
 };
 
@@ -350,6 +351,25 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // wave reduction is amortised over twice the pair evaluations); the backward kernels gain nothing from it
     L.fkpt = L.kpt; L.fnw = L.nw;
     if (even4 && NU > 512 && NU <= 1024) { L.fkpt = 4; L.fnw = 4; }
+    // Forward of the complex-modulus models: dense prefix [0, Kd) of the pool on the outer-product register tile, the sparse
+    // fringe on the row-tile kernel in the same launch (score_pool_tile.h).  Needs the 4-wave forward configuration (rows of
+    // 257 .. 1024 complex dims), whole 64-position tiles in the prefix (K = P / 2 >= 64) and 16-byte rows.
+    L.tile = 0; L.tile_kd = 0; L.tile_ks = 1; L.tile_fringe_slices = 1;
+    {
+        static const bool off = getenv("MKB_POOL_TILE") && getenv("MKB_POOL_TILE")[0] == '0';  // A/B switch
+        const int64_t Kd = (P / 2) / 64 * 64;
+        if (!off && cp && !use_mfma(tb) && al16 && d % 4 == 0 && L.fnw == 4 && (L.fkpt == 4 || L.fkpt == 2) && Kd >= 64 && B >= 64) {
+            L.tile = 1;
+            L.tile_kd = (int)Kd;
+            const int tiles = (int)((B + 63) / 64) * (int)(Kd / 64);
+            int ks = 1;
+            while (tiles * ks < 512 && ks < 16 && d / (ks * 2) >= 32) ks *= 2;  // fill the chip; >= 2 chunks of 16 dims per split
+            if (const char *e = getenv("MKB_POOL_TILE_KS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ks = v; }
+            L.tile_ks = ks;
+            L.tile_fringe_slices = 2;
+            if (const char *e = getenv("MKB_POOL_TILE_FSL")) { const int v = atoi(e); if (v >= 1 && v <= 16) L.tile_fringe_slices = v; }
+        }
+    }
     const int target = 256 * 16 / L.nw;  // workgroups for ~16 waves per CU
     const int row_tiles = (int)((B + TI - 1) / TI), pos_tiles = (int)((P + TI - 1) / TI);
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -434,6 +454,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     w.rel_rep = take(L.rel_copies > 1 ? (size_t)L.rel_copies * L.rel_elems * 4 : 0);
     w.occ = (int *)take((size_t)L.n_entity * 4);
     w.depth = (int *)take(L.mfma ? (size_t)B * 4 : 0);
+    w.tile_part = take(L.tile ? (size_t)L.tile_ks * B * L.tile_kd * 4 : 0);  // dim-split partial scores of the dense prefix
     w.bytes = off;
     return w;
 }
@@ -556,6 +577,11 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
     A.S = S;
     if (occ) { A.occ = occ; A.occ_sample = sample; if (occ_counted) *occ_counted = true; }
     ProfScope ps(MKB_PROF_POOL_FWD, st);
+    if (L.tile) {  // (s_tail: the loss rows of mkb_pool_step add the prefix's partial sums up; otherwise S is finished here)
+        A.tile_part = w.tile_part;
+        A.tile_tail = s_tail;
+        return launcher_of(tb->model)(5, head, L, A, st);
+    }
     return launcher_of(tb->model)(0, head, L, A, st);
 }
 
@@ -767,5 +793,5 @@ extern "C" int mkb_pool_step(const mkb_tables_t *tb, const mkb_grads_t *gr, cons
     if (int rc = pool_step_fwd(tb, sample, pool, cnt, B, K, mode, pos_score, pool_score, ws, stream, no_fold ? nullptr : &s_tail))
         return rc;
     return pool_step_bwd(tb, gr, sample, weight, pool, cnt, B, K, mode, alpha, weight_sum, pos_score, pool_score, loss, ws,
-                         stream, s_tail.kind == 1 ? &s_tail : nullptr);
+                         stream, (s_tail.kind == 1 || s_tail.kind == 3) ? &s_tail : nullptr);
 }

@@ -52,6 +52,9 @@ struct PoolArgs {
     float *g_modulus;      // pRotatE
     const float *modulus;  // pRotatE
     int B, P, d, x_slices, q_slices;  // q_slices: dQ partial buffers (= position blocks of the single-pass backward)
+    int p_lo;                         // forward: first pool position this launch's sparse workgroups cover (0 = the whole pool)
+    float *tile_part;                 // forward tile (host side): partial-sum buffer and where to describe the pending reduction
+    GemmTail *tile_tail;
     int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
     int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
     float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
@@ -180,16 +183,17 @@ __device__ __forceinline__ void store_units(float *__restrict__ row, int d, int 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Body of one (row tile bx of n_bx, position slice sl of nsl) workgroup over the pool positions [A.p_lo, A.P) -- the whole
+// pool for pool_fwd_kernel, the sparse fringe behind the dense prefix when it rides pool_fwd_tile_kernel's launch.
 template <int MODEL, bool HEAD, int KPT, int NW>
-__global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
+__device__ __forceinline__ void pool_fwd_body(const PoolArgs &A, const int bx, const int n_bx, const int sl, const int nsl, int *lds_dyn) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int WG = NW * 64;
-    // position slice of this workgroup: p = slice + nslices * i (interleaved, so every slice gets the same share of the
+    // position slice of this workgroup: p = p_lo + slice + nslices * i (interleaved, so every slice gets the same share of the
     // low, heavily used positions); only those are listed: LDS (and the list-building work) shrink with the slices
-    const int nsl = gridDim.y, sl = blockIdx.y;
-    const int Pn = (A.P - sl + nsl - 1) / nsl;
-    const int Pcap = (A.P + nsl - 1) / nsl;
-    extern __shared__ __attribute__((aligned(16))) int lds_dyn[];  // sized by the launch: 3 * ceil(P / nslices) words
+    const int Pw = A.P - A.p_lo;
+    const int Pn = (Pw - sl + nsl - 1) / nsl;
+    const int Pcap = (Pw + nsl - 1) / nsl;
     int *s_row = lds_dyn;                                           // entity id per active position
     int *s_pos = lds_dyn + Pcap;                                    // pool position
     unsigned *s_mask = reinterpret_cast<unsigned *>(lds_dyn + 2 * Pcap);  // bit r: row r of the tile uses it
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
     __shared__ int s_wave_cnt[NW];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * TI;
+    const int i0 = bx * TI;
     const int NU = CP ? A.d : (int)A.De;
     const int u0 = tid * KPT;
 
@@ -218,14 +222,14 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
             atomicAdd(A.occ + A.occ_sample[3 * (int64_t)(i0 + tid)], 1);
             atomicAdd(A.occ + A.occ_sample[3 * (int64_t)(i0 + tid) + 2], 1);
         }
-        for (int p = blockIdx.x * WG + tid; p < A.P; p += gridDim.x * WG) atomicAdd(A.occ + A.pool[p], 1);
+        for (int p = bx * WG + tid; p < A.P; p += n_bx * WG) atomicAdd(A.occ + A.pool[p], 1);
     }
 
     // positions used by at least one row of the tile, compacted into LDS
     MKB_TRACE_T(tr_t0);
     int n_act = 0;
     for (int base = 0; base < Pn; base += WG) {
-        const int p = sl + (base + tid) * nsl;
+        const int p = A.p_lo + sl + (base + tid) * nsl;
         unsigned m_own = 0;
         if (base + tid < Pn) {
             unsigned c[TI];
@@ -330,6 +334,12 @@ __global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
         }
     }
     MKB_TRACE_OUT(A, 0, tr_t0, tr_t1, wall_clock64(), n_mine);
+}
+
+template <int MODEL, bool HEAD, int KPT, int NW>
+__global__ __launch_bounds__(NW * 64) void pool_fwd_kernel(PoolArgs A) {
+    extern __shared__ __attribute__((aligned(16))) int lds_fwd[];  // sized by the launch: 3 * ceil(P / nslices) words
+    pool_fwd_body<MODEL, HEAD, KPT, NW>(A, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y, lds_fwd);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dq
@@ -1038,13 +1048,14 @@ struct PoolLaunch {
     int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the five below
     int bkpt;             // its units per lane (1, 2, or 4 for real-valued models with long rows)
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
+    int tile, tile_kd, tile_ks, tile_fringe_slices;  // forward: dense prefix [0, tile_kd) on the register tile (score_pool_tile.h)
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
     int64_t n_entity;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
-typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd, 5 fwd: tile + fringe*/, bool head, const PoolLaunch &L, const PoolArgs &A,
                               hipStream_t st);
 int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
 int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
@@ -1101,7 +1112,11 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
 }
 
 template <int MODEL, bool HEAD>
+static int launch_fwd_tile(const PoolLaunch &L, const PoolArgs &A, hipStream_t st, float *part, GemmTail *tail);  // score_pool_tile.h
+
+template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
+    if (which == 5) return launch_fwd_tile<MODEL, HEAD>(L0, A, st, A.tile_part, A.tile_tail);
     if (which == 4) {
         if constexpr (!ModelTraits<MODEL>::cplx_pair)
             if (L0.bkpt == 4) return launch_bwd1<MODEL, HEAD, 4>(L0, A, st);
