@@ -528,6 +528,14 @@ def roofline_of(res, world, want_traffic):
             "note": (f"{label}: " + (f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}"
                                      if mfma else f"{pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop")
                      + "; peak = fp32 vector / matrix rate of MI355X")}
+    if MODEL == "RotatE":
+        # ceiling at the instruction rates MEASURED on this part (tools/ubench/trans_rate.hip, profiles/r03_instruction_rates_and_
+        # tile_ubench.txt: v_pk_*_f32 2.17 ns, v_sqrt / v_rsq 3.58 ns per wave64 instruction and SIMD, SIMDs saturated): the pair
+        # body is 5 packed + 2 v_sqrt per two terms forward, 9 packed + 2 v_rsq backward, on 1024 SIMDs
+        body_ns = (9 if bwd else 5) * 2.17 + 2 * 3.58
+        floor_us = float(pairs) * units / 2.0 / 64.0 / 1024.0 * body_ns / 1e3
+        roof["issue_floor_us"] = floor_us
+        roof["frac_of_issue_floor"] = floor_us / (avg_s * 1e6)
     if MODEL == "TransE":
         roof["bound_note"] = ("2-4 flop per 4-byte pair term: the kernel is bound by moving operands (L2 -> registers, LDS "
                               "read-modify-write of dx), not by the VALU; the fraction of the fp32 peak is reported for continuity only")
