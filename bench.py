@@ -125,7 +125,7 @@ def run_step(ctx, i):
         lo = ((i * world + rank) * Bl) % (n - Bl)
         sample, weight = ctx["train"][lo: lo + Bl], ctx["weights"][lo: lo + Bl]
         nlo = (((i + 1) * world + rank) * Bl) % (n - Bl)  # the next batch: its routing is prepared while this step runs
-        loss = ctx["step"](sample, weight, ctx["sampler"].generate(sample, mode), mode, next_sample=ctx["train"][nlo: nlo + Bl])
+        loss = ctx["step"].sampled(sample, weight, ctx["sampler"], mode, next_sample=ctx["train"][nlo: nlo + Bl])
         ctx["opt"].step()
         ctx["opt"].zero_grad()
         return loss

@@ -274,6 +274,15 @@ int mkb_adam_rows_advance_sharded(float *param, float *grad, float *exp_avg, flo
                                   float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead,
                                   void *stream);
 
+/* ... and with this rank's mkb_sampler_generate riding the same launch (the pool ids are the sampler's own): the sharded
+ * counterpart of mkb_adam_rows_advance_generate / _catchup_generate (grad == null). */
+int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last,
+                                           float *consts, int64_t n_rows, int64_t D, int world, int rank,
+                                           const int64_t *local_ids, int64_t n_local_ids, int64_t step_upto, float lr,
+                                           float beta1, float beta2, float eps, const mkb_adam_dense_t *rider,
+                                           mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
+                                           int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream);
+
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the
  * candidate list and filter bias of datasets.base.TestDataset (datasets/base.py:196-241): for each test triple

@@ -107,6 +107,10 @@ _SIGNATURES = {
     "mkb_adam_rows_advance_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                               c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_float, c_float,
                                               c_float, c_float, POINTER(AdamDense), c_void_p, c_void_p]),
+    "mkb_adam_rows_advance_sharded_generate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                                       c_int, c_int, c_void_p, c_int64, c_int64, c_float, c_float, c_float, c_float,
+                                                       POINTER(AdamDense), c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_check_ids": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "mkb_kl_divergence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),

@@ -470,7 +470,8 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
                                  int64_t D, int64_t step_upto, float lr, float beta1, float beta2, float eps,
                                  const mkb_adam_dense_t *rider, mkb_sampler_t *sampler, const int64_t *sample, int64_t B,
                                  int mode, int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
-                                 void *stream) {
+                                 void *stream, int own_world = 0, int own_rank = 0, const int64_t *local_ids = nullptr,
+                                 int64_t n_local_ids = 0) {
     hipStream_t st = (hipStream_t)stream;
     AdamRowArgs A{};
     if (int rc = fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, nullptr, D, step_upto > 0 ? step_upto : 0, lr,
@@ -482,6 +483,14 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
     A.first_row_block = 1;
     A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
     A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
+    if (own_world > 0) {
+        // shard of a row-sharded table: the rows to visit are the pool ids this rank owns (the sampler's pool buffer holds
+        // GLOBAL ids) followed by the shard indices other ranks asked for; the batch's own heads / tails live elsewhere
+        MKB_REQUIRE(own_rank >= 0 && own_rank < own_world && (local_ids || n_local_ids == 0) && n_local_ids >= 0, "bad ownership");
+        A.own_ids = A.seg_pool; A.own_n = A.filt.P; A.own_world = own_world; A.own_rank = own_rank;
+        A.ids = local_ids; A.seg_pool = nullptr;
+        set_row_blocks(A, step_upto > 0 ? (int64_t)A.own_n + n_local_ids : 0);
+    } else
     set_row_blocks(A, step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0);  // nothing is pending before the first step
     const int64_t rows = A.n_ids;
     int64_t extra = 0;
@@ -552,6 +561,23 @@ extern "C" int mkb_adam_rows_advance_generate(float *param, float *grad, float *
     MKB_REQUIRE(grad, "null gradient (use mkb_adam_rows_catchup_generate)");
     return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, D, step_upto, lr, beta1, beta2, eps, rider,
                                       sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream);
+}
+
+// mkb_adam_rows_advance_sharded with this rank's mkb_sampler_generate (filter of its rows + the next pool's draw) in the same
+// launch: global_ids are the sampler's own pool.  grad == null: plain catch-up.
+extern "C" int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last,
+                                                      float *consts, int64_t n_rows, int64_t D, int world, int rank,
+                                                      const int64_t *local_ids, int64_t n_local_ids, int64_t step_upto, float lr,
+                                                      float beta1, float beta2, float eps, const mkb_adam_dense_t *rider,
+                                                      mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode,
+                                                      int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
+                                                      void *stream) {
+    (void)n_rows;
+    MKB_REQUIRE(world >= 1, "bad world");
+    MKB_REQUIRE(grad || !rider, "a dense rider needs the advance form (grad != null)");
+    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, D, step_upto, grad ? lr : 0.f, beta1, beta2,
+                                      eps, rider, sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream, world, rank,
+                                      local_ids, n_local_ids);
 }
 
 extern "C" int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,

@@ -121,6 +121,23 @@ class Adam:
                 self.eps, self._take_dense() if defer else None, self._sampler_handle(p.device), _hip.stream_ptr()),
                 "mkb_adam_rows_advance_sharded")
 
+    def catch_up_sharded_generate(self, p, world, rank, local_ids, sampler_handle, sample, B, mode_id, neg, pool, pos, cnt, touched):
+        """``catch_up_sharded(p, the sampler's pool, world, rank, local_ids)`` fused with the sampler's filter of this rank's rows
+        and the draw of the next pool: one launch (``mkb_adam_rows_advance_sharded_generate``)."""
+        st = self._state(p)
+        upto = st["n"]
+        st["caught_up"] = (None, upto)
+        lib, c = _hip.lib(), self._consts(st, max(upto, 1))
+        defer = bool(st.get("defer"))
+        n_loc = 0 if local_ids is None else local_ids.numel()
+        with torch.cuda.device(p.device):
+            _hip.check(lib.mkb_adam_rows_advance_sharded_generate(
+                _hip.ptr(p.data), _hip.ptr(st["g"]) if defer else None, _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
+                _hip.ptr(c), p.shape[0], p.shape[1], world, rank, _hip.ptr(local_ids) if n_loc else None, n_loc, upto,
+                self._lr_of(st, upto), self.betas[0], self.betas[1], self.eps, self._take_dense() if defer else None,
+                sampler_handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg), _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt),
+                _hip.ptr(touched), _hip.stream_ptr()), "mkb_adam_rows_advance_sharded_generate")
+
     def catch_up_generate(self, p, sampler_handle, sample, B, mode_id, neg, pool, pos, cnt, touched):
         """``catch_up(p, rows of this batch)`` fused with the sampler's filter + next-pool draw (one launch; see
         ``sampling.NegativeSampling.generate_with_catch_up``)."""

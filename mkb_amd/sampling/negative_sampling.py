@@ -186,6 +186,27 @@ class NegativeSampling:
         neg._mkb_pool.touched = touched
         return neg
 
+    def generate_with_sharded_catch_up(self, sample, mode, optimizer, param, world, rank, local_ids):
+        """``generate(sample, mode)`` for this rank's rows of a global batch and ``optimizer.catch_up_sharded(param, pool, world,
+        rank, local_ids)`` for a ROW SHARD of the entity table (``mkb_amd.table_rows``) as one launch that also draws the next
+        pool.  Same negatives, pool and multiplicities, bit for bit, as ``generate``."""
+        if mode not in ("head-batch", "tail-batch"):
+            raise ValueError("mode must be 'head-batch' or 'tail-batch'")
+        sample = _hip.contiguous(sample, torch.int64)
+        _hip.require_device(param, sample)
+        dev = sample.device
+        self._ensure_handle(dev)
+        B, K = sample.shape[0], self.size
+        neg = torch.empty((B, K), dtype=torch.int64, device=dev)
+        pool = torch.empty(2 * K, dtype=torch.int64, device=dev)
+        pos = torch.empty((B, K), dtype=torch.int32, device=dev)
+        cnt = torch.empty((B, 2 * K), dtype=torch.uint16, device=dev)
+        touched = torch.empty(2 * K + 2 * B, dtype=torch.int64, device=dev)  # (global ids: unused by the sharded caller)
+        mode_id = _hip.mode_id(mode)
+        optimizer.catch_up_sharded_generate(param, world, rank, local_ids, self._handle, sample, B, mode_id, neg, pool, pos, cnt, touched)
+        neg._mkb_pool = PoolInfo(pool, pos, cnt, K, mode_id, sample)
+        return neg
+
     def check(self):
         """Raise what the reference would have raised for the batches generated so far (synchronises)."""
         if self._handle is None:

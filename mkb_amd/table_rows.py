@@ -353,12 +353,24 @@ class TableRowShardedStep:
                                                 _hip.stream_ptr()), "mkb_pool_step")
         self.positive_score, self._S = pos, S
 
-    def __call__(self, sample, weight, negative_sample, mode, next_sample=None):
-        info = negative_sample._mkb_pool
+    def sampled(self, sample, weight, sampler, mode, next_sample=None):
+        """``step(sample, weight, sampler.generate(sample, mode), mode, next_sample)`` with the sampler folded into the shard's
+        optimizer launch when the shard steps row-lazily (``mkb_adam_rows_advance_sharded_generate``: filter of this rank's rows
+        + draw of the next pool + catch-up of the rows about to be read, one launch); identical negatives.  They stay
+        available as ``self.negative_sample``."""
+        opt = _links.owner(self.table.data)
+        if opt is None or self.compute is not None or sampler.size > 512 or not sample.is_cuda:
+            neg = sampler.generate(sample, mode)
+            self.negative_sample = neg
+            return self(sample, weight, neg, mode, next_sample=next_sample)
+        return self(sample, weight, None, mode, next_sample=next_sample, _sampler=sampler)
+
+    def __call__(self, sample, weight, negative_sample, mode, next_sample=None, _sampler=None):
         tb, ops, dev = self.table, self.ops, sample.device
         sample = sample if sample.is_contiguous() else sample.contiguous()
         weight = weight if weight.is_contiguous() else weight.contiguous()
-        b, P = sample.shape[0], info.pool.numel()
+        b = sample.shape[0]
+        P = 2 * _sampler.size if _sampler is not None else negative_sample._mkb_pool.pool.numel()
         self._last_P = P
         D, X, row0, rows = self._layout(P, b)
         bufs = self._buffers(P, b, dev)
@@ -373,7 +385,12 @@ class TableRowShardedStep:
         touched = route.listed  # [P + R] shard indices written this step: pool rows (-1: not mine; filled in by the gather) | want
         if self._occ is None or self._occ.device != dev:
             self._occ = torch.zeros(tb.data.shape[0], dtype=torch.int32, device=dev)
-        if opt is not None:
+        if _sampler is not None:  # sampler + catch-up of [owned pool rows | requested rows] in one launch
+            negative_sample = _sampler.generate_with_sharded_catch_up(sample, mode, opt, tb.data, self.world, tb.rank, want)
+            self.negative_sample = negative_sample
+            opt._state(tb.data)["caught_up"] = (touched, opt._state(tb.data)["n"])
+        info = negative_sample._mkb_pool
+        if opt is not None and _sampler is None:
             opt.catch_up_sharded(tb.data, info.pool, self.world, self.rank_of_table, want)
             opt._state(tb.data)["caught_up"] = (touched, opt._state(tb.data)["n"])
         reply = torch.empty((R, D), dtype=torch.float32, device=dev)

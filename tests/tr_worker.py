@@ -47,9 +47,12 @@ def main():
             lo, hi = rank * B // world, (rank + 1) * B // world
             todo = [(s[lo:hi].contiguous(), w[lo:hi].contiguous(), mode) for s, w, mode in batches()]
             for i, (sl, wl, mode) in enumerate(todo):
-                neg = ns.generate(sl, mode)  # one pool draw per call on every rank: identical pools, own rows filtered
                 nxt = todo[i + 1][0] if i + 1 < len(todo) and i != 2 else None  # routes planned one batch ahead (and once not)
-                losses.append(step(sl, wl, neg, mode, next_sample=nxt).item())
+                if big and i % 2 == 1:  # the sampler riding the shard's optimizer launch (identical negatives)
+                    losses.append(step.sampled(sl, wl, ns, mode, next_sample=nxt).item())
+                else:
+                    neg = ns.generate(sl, mode)  # one pool draw per call on every rank: identical pools, own rows filtered
+                    losses.append(step(sl, wl, neg, mode, next_sample=nxt).item())
                 opt.step()
                 opt.zero_grad()
             opt.flush()
