@@ -111,42 +111,48 @@ __global__ __launch_bounds__(256) void pair_tile_bwd_kernel(Args A) {
             for (int a = 0; a < 4; ++a) q[a] = *reinterpret_cast<const float4 *>(&sq[kp][(wr + lr + 8 * a) * 4]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[c] = *reinterpret_cast<const float4 *>(&sx[buf][kp][(wp + lp + 8 * c) * 4]);
-            f2 dqr[4], dqi[4], dxr[4], dxi[4];
+            // positions outer, rows inner: a position's dx is complete after its 4 rows and goes through its reduction at
+            // once (2 live f2 instead of 8); dq of the 4 rows accumulates across the positions
+            f2 dqr[4], dqi[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dqr[j] = f2{0.f, 0.f}; dqi[j] = f2{0.f, 0.f}; dxr[j] = f2{0.f, 0.f}; dxi[j] = f2{0.f, 0.f}; }
+            for (int j = 0; j < 4; ++j) { dqr[j] = f2{0.f, 0.f}; dqi[j] = f2{0.f, 0.f}; }
             const f2 eps = f2{1e-30f, 1e-30f};
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int c = 0; c < 4; ++c) {
+                f2 dxr = f2{0.f, 0.f}, dxi = f2{0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int a = 0; a < 4; ++a) {
                     const f2 da = f2{q[a].x, q[a].y} - f2{x[c].x, x[c].y}, db = f2{q[a].z, q[a].w} - f2{x[c].z, x[c].w};
                     const f2 n2 = __builtin_elementwise_fma(db, db, __builtin_elementwise_fma(da, da, eps));
                     const f2 w = f2{__builtin_amdgcn_rsqf(n2.x), __builtin_amdgcn_rsqf(n2.y)} * g[a][c];
                     dqr[a] = __builtin_elementwise_fma(-w, da, dqr[a]);
                     dqi[a] = __builtin_elementwise_fma(-w, db, dqi[a]);
-                    dxr[c] = __builtin_elementwise_fma(w, da, dxr[c]);
-                    dxi[c] = __builtin_elementwise_fma(w, db, dxi[c]);
+                    dxr = __builtin_elementwise_fma(w, da, dxr);
+                    dxi = __builtin_elementwise_fma(w, db, dxi);
                 }
-            // dq: 16 floats (row a: re_k, re_k+1, im_k, im_k+1) summed over the 8 lanes sharing lr
+#ifdef NO_DXRED
+                const float4 u = make_float4(dxr.x, dxr.y, dxi.x, dxi.y);
+#else
+                const float4 u = make_float4(sum_lr(dxr.x), sum_lr(dxr.y), sum_lr(dxi.x), sum_lr(dxi.y));
+#endif
+#ifdef NO_DXLDS
+                if (u.x == 12345.f) sdx[wave][0][0][0] = u.y + u.z + u.w;
+#else
+                if (lr == kp) *reinterpret_cast<float4 *>(&sdx[wave][lp + 8 * c][kp][0]) = u;
+#endif
+            }
             float v[16], r[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) { v[4 * a] = dqr[a].x; v[4 * a + 1] = dqr[a].y; v[4 * a + 2] = dqi[a].x; v[4 * a + 3] = dqi[a].y; }
+#ifdef NO_DQRED
+            r[0] = v[0] + v[4] + v[8] + v[12]; r[1] = v[1] + v[5] + v[9] + v[13]; r[2] = v[2] + v[6] + v[10] + v[14]; r[3] = v[3] + v[7] + v[11] + v[15];
+#else
             reduce_dq(v, r);
+#endif
             if ((lane & 8) == 0) {
                 float4 t = *reinterpret_cast<const float4 *>(&sdq[wave][dq_row][kp][0]);
                 t.x += r[0]; t.y += r[1]; t.z += r[2]; t.w += r[3];
                 *reinterpret_cast<float4 *>(&sdq[wave][dq_row][kp][0]) = t;
-            }
-            // dx: 16 floats summed over the 8 lanes sharing lp; lane lr == kp keeps them (LDS image [pos][kp][4])
-            float u[16];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u[4 * c] = sum_lr(dxr[c].x); u[4 * c + 1] = sum_lr(dxr[c].y); u[4 * c + 2] = sum_lr(dxi[c].x); u[4 * c + 3] = sum_lr(dxi[c].y);
-            }
-            if (lr == kp) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<float4 *>(&sdx[wave][lp + 8 * c][kp][0]) = make_float4(u[4 * c], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
             }
         }
         if (pt + 1 < n_pt) lstore(buf ^ 1);
