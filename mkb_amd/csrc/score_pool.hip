@@ -646,7 +646,7 @@ static int check_pool_call(const mkb_tables_t *tb, const int64_t *sample, const 
     MKB_REQUIRE(mode == MKB_MODE_HEAD || mode == MKB_MODE_TAIL, "the pooled path needs head-batch or tail-batch");
     MKB_REQUIRE((((uintptr_t)ws) & 255) == 0, "workspace must be 256-byte aligned");
     if (2 * K > kMaxP || !pick_config(tb, B, 2 * K, L))
-        return set_error(MKB_ERR_UNSUPPORTED, "shape not covered by the pooled kernels (size <= 512, rows <= 4096 units, "
+        return set_error(MKB_ERR_UNSUPPORTED, "shape not covered by the pooled kernels (size <= 1024, rows <= 4096 units, "
                                               "even dims above 256 units); use the general path");
     return MKB_OK;
 }

@@ -35,7 +35,7 @@ constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions
 constexpr int kRing1 = 3;   // candidate rows in flight per lane in the single-pass backward
 constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8 rows / positions takes the branch-free body
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
-constexpr int kMaxP = 1024; // pool positions supported by the LDS tile lists
+constexpr int kMaxP = 2048; // pool positions supported (= the device sampler's limit, size <= 1024)
 constexpr int kMaxSlices = 8;
 
 struct DxReduce;

@@ -497,30 +497,38 @@ def test_fused_step_edge_shapes_with_wrapping_rows(name, B, K, hidden):
     assert wrapped, "the test is meant to exercise multiplicities > 1"
 
 
-def test_large_pool_falls_back_to_general_kernels():
-    """size > 512 is outside the pooled kernels: model(...) must silently take the general path, same numbers."""
-    from mkb_amd import datasets, losses, models, sampling
-    from mkb_amd.fused import pooled_supported
+@pytest.mark.parametrize("name,hidden,B,K", [("TransE", 20, 8, 600), ("RotatE", 40, 70, 600), ("ComplEx", 24, 64, 700),
+                                             ("pRotatE", 16, 33, 1024), ("RotatE", 300, 64, 640)])
+def test_large_pools_run_on_the_pooled_kernels(name, hidden, B, K):
+    """512 < size <= 1024 (pools of up to 2048 positions, the device sampler's limit): the pooled kernels cover them since
+    round 3 (two-pass backward where the single-pass accumulator does not fit, the loss rows re-reading long rows).  Scores
+    through model(...), then the fused step's loss and gradients, against the oracle; negatives against the oracle sampler."""
+    from mkb_amd.fused import FusedTrainStep, pooled_supported
+    from oracle import sampler as osamp
     from oracle import scoring
 
-    ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
-    torch.manual_seed(1)
-    m = models.TransE(hidden_dim=20, entities=ds.entities, relations=ds.relations, gamma=6.0)
-    tb = scoring.Tables("TransE", 20, 6.0, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone())
-    m = m.cuda()
-    K = 600
-    assert not pooled_supported(m, 8, K)
-    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
-    s = torch.tensor(ds.train[:8]).cuda()
-    neg = ns.generate(s, "tail-batch")
-    got = m(s, neg, "tail-batch")
-    ref = scoring.score(tb, s.cpu(), neg.cpu(), "tail-batch")
-    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=ATOL)
-    # and the oracle sampler agrees at this size too
-    from oracle import sampler as osamp
+    ds, m, tb, ns, train = _setup("Fb15k237", name, hidden, B, K, gamma=9.0)
+    assert pooled_supported(m, B, K)
+    idx = torch.as_tensor(np.random.RandomState(5).randint(len(train), size=B))
+    s = train[idx].cuda()
+    w = (torch.rand(B) + 0.1).cuda()
     on = osamp.NegativeSampling(K, ds.train, ds.entities, ds.relations, seed=42)
-    want, _ = on.generate(s.cpu().numpy(), "tail-batch")
-    np.testing.assert_array_equal(neg.cpu().numpy(), want)
+    for mode in ("head-batch", "tail-batch"):
+        neg = ns.generate(s, mode)
+        want, _ = on.generate(s.cpu().numpy(), mode)
+        np.testing.assert_array_equal(neg.cpu().numpy(), want)
+        assert neg._mkb_pool.usable_for(m, s, neg._mkb_pool.mode_id)
+        got = m(s, neg, mode)
+        ref = scoring.train_step_grads(tb, s.cpu(), neg.cpu(), w.cpu(), mode, 1.0, fast_norm=True)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        m.zero_grad(set_to_none=True)
+        step = FusedTrainStep(m, alpha=1.0)
+        loss = step(s, w, neg, mode)
+        np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
+        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+    ns.check()
 
 
 @pytest.mark.parametrize("name,hidden", [("RotatE", 1000), ("ComplEx", 1000), ("TransE", 1000)])
