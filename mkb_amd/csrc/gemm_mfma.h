@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__rest
 // tail: non-null = the caller folds a split-K reduction / scatter into its next launch (GemmTail, common.h): it is described
 // there instead of being launched (kind 0 when the product needed none).
 template <bool A_MK, bool B_NK, int EPI>
-static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr) {
+static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr, int want_wg = 0) {
     if (tail) tail->kind = 0;
     {   // 128 x 128 / 128 x 64 tiles (4 / 2 accumulators per wave) when the operands allow 16-byte loads
         static const bool off = getenv("MKB_GEMM_NO128") != nullptr;  // A/B switch
@@ -364,7 +364,10 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             const bool narrow = tiles128 < 200;
             const int tiles = narrow ? ((G.M + 127) / 128) * ((G.N + 63) / 64) : tiles128;
             int ks = 1;
-            static const int min_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 200;  // experiment knob
+            // workgroups wanted: ~1 per CU by default; the score product asks for 2 (want_wg = 500: a lone 4-wave workgroup leaves
+            // each SIMD's matrix pipe idle during its staging; measured 37 -> 29 us, the split-K sum rides the loss rows anyway)
+            static const int env_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 0;  // experiment knob
+            const int min_wg = env_wg ? env_wg : (want_wg ? want_wg : 200);
             while (tiles * ks < min_wg && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
             G.ksplit = ks;
             float *final_c = G.C;

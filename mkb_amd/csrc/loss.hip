@@ -125,8 +125,14 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
             const bool ok = j < K;
             c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
             float acc = 0.f;
-            if (ok)
-                for (int z = 0; z < NT.nz; ++z) acc += NT.part[(int64_t)z * NT.n + (int64_t)i * K + j];
+            if (ok) {  // <= 8 splits: their loads issued together (a run-time trip count made them one round trip each)
+                const float *pp = NT.part + (int64_t)i * K + j;
+                float pz[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) pz[z] = pp[(int64_t)min(z, NT.nz - 1) * NT.n];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) acc += z < NT.nz ? pz[z] : 0.f;  // fixed order: deterministic
+            }
             v[t] = ok ? NT.c0 + NT.c1 * acc : 0.f;
             if (ok) NT.out[(int64_t)i * K + j] = v[t];
         }

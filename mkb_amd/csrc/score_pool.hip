@@ -571,7 +571,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
         g.C = S; g.ldc = P; g.M = (int)B; g.N = (int)P; g.K = (int)tb->entity_dim; g.c0 = 0.f; g.c1 = 1.f;
         if (cut) { g.depth = w.depth; g.depth_mode = 1; g.n_depth = (int)B; }
         ProfScope ps(MKB_PROF_POOL_FWD, st);
-        return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part, s_tail);
+        return launch_gemm<true, true, GEMM_STORE_AFFINE>(g, st, w.gemm_part, s_tail, s_tail ? 500 : 0);
     }
     PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);  // (the kernel also zero-fills the entries no row uses)
     A.S = S;
@@ -606,7 +606,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
             if (cut) { g.depth = w.depth; g.depth_mode = 3; g.n_depth = (int)B; }
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
-            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part, x_tail)) return rc;
+            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part, x_tail, x_tail ? 500 : 0)) return rc;
         }
     } else {
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
