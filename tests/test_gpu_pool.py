@@ -63,6 +63,8 @@ def test_pooled_forward_backward_equals_general_and_oracle(name, mode):
     ("Fb15k237", "ComplEx", 40, 160, 256),    # config 4
     ("Fb15k237", "DistMult", 33, 96, 256),
     ("Fb15k237", "pRotatE", 24, 96, 256),
+    ("Fb15k237", "RotatE", 260, 100, 96),     # forward tile with ragged edges: B not a multiple of 64 (or 8), K not of 64, 260 dims
+    ("Wn18rr", "RotatE", 512, 67, 64),        # ... one 64-position tile, 4 units per lane, a single row tile
 ])
 def test_fused_step_vs_oracle_real_graphs(cls, name, hidden, B, K):
     from mkb_amd.fused import FusedTrainStep
