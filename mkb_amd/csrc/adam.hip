@@ -10,6 +10,7 @@
 #include "sampler_draw.h"
 
 #include <math.h>
+#include <algorithm>
 
 namespace mkb {
 
@@ -141,6 +142,10 @@ struct AdamRowArgs {
     // row e lives on rank e % own_world at index e / own_world; entries another rank owns are skipped.  `ids` follows them.
     const int64_t *own_ids;
     int32_t own_n, own_world, own_rank;
+    // sweep: the listed rows [n_batch_rows, n_rows_listed) are table rows sweep_start, sweep_start + 1, ... (mod n_table) --
+    // a window that moves through the table once per kSweepPeriod steps, so that no row's pending list outgrows the period
+    int32_t n_batch_rows, sweep_start;
+    int64_t n_table;
 };
 
 __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v, float w1, float b2, float neg_step,
@@ -160,6 +165,10 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
 #define MKB_CATCH_THREADS 1024
 #endif
 constexpr int kCatchThreads = MKB_CATCH_THREADS;
+#ifndef MKB_REPLAY_UNROLL
+#define MKB_REPLAY_UNROLL 4
+#endif
+constexpr int kReplayUnroll = MKB_REPLAY_UNROLL;  // pending zero-gradient steps replayed side by side
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // adam_one / adam_zero_grad_step on two elements at once (v_pk_* where the scalar code has v_*: the same IEEE operations,
@@ -177,7 +186,8 @@ __device__ __forceinline__ void adam_pair(f2 &p, f2 g, f2 &m, f2 &v, float w1, f
 __device__ __forceinline__ void adam_pair_zero_grad(f2 &p, f2 &m, f2 &v, float w1, float b2, float neg_step, float inv_bc2,
                                                     float eps) {
 #pragma clang fp contract(off)
-    m = __builtin_elementwise_fma(f2{w1, w1}, f2{0.f, 0.f} - m, m);
+    // (0 - m) as a source modifier: 0 - m and -m differ only for m = +-0, where w1 * (+-0) + m gives the same +0 / -0 sum
+    m = __builtin_elementwise_fma(f2{w1, w1}, -m, m);
     v = v * b2;  // (+ (w2 * 0) * 0 adds +0 to a non-negative number)
     const f2 denom = f2{__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)} * inv_bc2 + eps;
     p = p + (neg_step * m) * f2{__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
@@ -254,6 +264,35 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
         }
         ++s;
     }
+    // Zero-gradient steps.  `from` / `to` are wave-uniform (scalar registers), so the per-step constants come through the
+    // scalar cache; they are fetched kReplayUnroll steps ahead of their use, and the steps of a group are written out side by
+    // side: per element the only serial links between steps are ONE multiply (v), ONE fma (m) and ONE add (p) -- the
+    // sqrt / rcp chains of neighbouring steps overlap.  (Before: one vector load round trip + a 7-deep chain per step; the
+    // launch lasted as long as the row with the longest gap -- WN18RR: ~900 pending steps.)
+    const int last_tab = A.g ? to - 1 : to;  // the advance form's own step is recorded by this very launch: not in the table
+    if (s + kReplayUnroll - 1 <= last_tab) {
+        float2 nx[kReplayUnroll];
+#pragma unroll
+        for (int u = 0; u < kReplayUnroll; ++u) nx[u] = A.consts[s + u];
+        for (;;) {
+            float2 cs[kReplayUnroll];
+#pragma unroll
+            for (int u = 0; u < kReplayUnroll; ++u) cs[u] = nx[u];
+            s += kReplayUnroll;
+            const bool more = s + kReplayUnroll - 1 <= last_tab;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < kReplayUnroll; ++u) nx[u] = A.consts[s + u];
+            }
+#pragma unroll
+            for (int u = 0; u < kReplayUnroll; ++u) {
+                const float inv = __builtin_amdgcn_rcpf(cs[u].y);
+#pragma unroll
+                for (int e = 0; e < EPL / 2; ++e) adam_pair_zero_grad(p[e], m[e], v[e], A.w1, A.b2, cs[u].x, inv, A.eps);
+            }
+            if (!more) break;
+        }
+    }
     for (; s <= to; ++s) {
         const float2 cs = replay_consts(A, s);
         const float inv = __builtin_amdgcn_rcpf(cs.y);
@@ -295,7 +334,7 @@ __device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t r
     if (valid && ahead && k0 < A.D) replay_load<EPL>(A, row, k0, c);
     __syncthreads();
     if (!valid) return;
-    const int old = *s_old;
+    const int old = __builtin_amdgcn_readfirstlane(*s_old);  // (whole waves per row: uniform)
     if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
     for (int64_t k = k0; k < A.D; k += (int64_t)EPL * lanes) {
         if (!ahead || k != k0) replay_load<EPL>(A, row, k, c);
@@ -330,7 +369,10 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
     bool valid = r < A.n_rows_listed;
     int64_t row = 0;
     if (valid) {
-        if (A.own_ids && r < A.own_n) {
+        if (r >= A.n_batch_rows) {
+            row = (int64_t)A.sweep_start + (r - A.n_batch_rows);
+            if (row >= A.n_table) row -= A.n_table;
+        } else if (A.own_ids && r < A.own_n) {
             const int64_t e = A.own_ids[r];
             row = (int)(e % A.own_world) == A.own_rank ? e / A.own_world : -1;
         } else if (A.own_ids) row = A.ids[r - A.own_n];
@@ -407,8 +449,31 @@ static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float 
 
 namespace mkb {
 
-static void set_row_blocks(AdamRowArgs &A, int64_t rows) {
-    const bool vec4 = (A.D & 3) == 0 && (((uintptr_t)A.p | (uintptr_t)A.m | (uintptr_t)A.v | (uintptr_t)A.g) & 15) == 0;
+// Sweep.  Exact dense Adam moves every parameter every step, so the replay's arithmetic is N x D element-steps per step no
+// matter when it happens (measured: ~85 ns per wave and pending step at 4 elements per lane: WN18RR +16 us, FB15k-237
+// +12 us, YAGO3-10 ~40 us per launch if spread evenly).  It is NOT spread evenly when entities are rare: a YAGO3-10 entity
+// that only the random pool reaches waits ~1,500 steps in the tail, its chain is serial, and the launch lasts as long as
+// its longest chain (99 us measured).  So when the mean gap N / rows-per-step is large, each per-step launch also visits
+// a moving window of N / period rows: every row is brought up to date at least once per `period` steps.  Same
+// arithmetic, same results bit for bit (every pending step of every row is replayed exactly once, whenever that happens);
+// cost: the window's rows x (p, m, v) in + out.  YAGO3-10: 99 -> 64 us per launch, step 0.268 -> 0.211 ms; WN18RR / FB15k-237
+// (mean gap 18 / 6 steps, every entity is a positive often enough): no gain, so no sweep.
+constexpr int kSweepPeriod = 64, kSweepMinGap = 32;
+
+static void set_row_blocks(AdamRowArgs &A, int64_t rows, int64_t n_table = 0) {
+    int64_t sweep = 0;
+    A.n_batch_rows = (int32_t)rows; A.sweep_start = 0; A.n_table = n_table;
+    if (rows > 0 && n_table > 0 && A.step > 0) {
+        const char *fe = getenv("MKB_ADAM_SWEEP");  // period, 0 = off (read per call: the tests switch it within one process)
+        const int forced = fe ? atoi(fe) : -1;
+        if (forced > 0) sweep = (n_table + forced - 1) / forced;
+        else if (forced < 0 && n_table >= (int64_t)kSweepMinGap * rows) sweep = std::min((n_table + kSweepPeriod - 1) / kSweepPeriod, rows);
+        if (sweep > 0) {
+            A.sweep_start = (int32_t)((((int64_t)A.step - 1) * sweep) % n_table);
+            rows += sweep;
+        }
+    }
+    bool vec4 = (A.D & 3) == 0 && (((uintptr_t)A.p | (uintptr_t)A.m | (uintptr_t)A.v | (uintptr_t)A.g) & 15) == 0;
     A.vec4 = vec4 ? 1 : 0;
     // as many rows per 1024-lane workgroup as fit with one chunk per lane (whole waves per row): 2000-float rows 2,
     // 1000-float rows 4, the 250-float rows of an 8-way dimension shard 8 -- short rows used to idle most of the lanes
@@ -452,7 +517,7 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
     }
     if (n <= 0 || step_upto <= 0) n = 0;  // nothing can be pending before the first step
     MKB_REQUIRE(n <= INT32_MAX, "too many rows");
-    set_row_blocks(A, n);
+    set_row_blocks(A, n, (ids || own_ids) ? n_rows : 0);  // (a flush walks the whole table anyway)
     n = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
@@ -467,7 +532,7 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
 }
 
 static int rows_advance_generate(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
-                                 int64_t D, int64_t step_upto, float lr, float beta1, float beta2, float eps,
+                                 int64_t n_rows, int64_t D, int64_t step_upto, float lr, float beta1, float beta2, float eps,
                                  const mkb_adam_dense_t *rider, mkb_sampler_t *sampler, const int64_t *sample, int64_t B,
                                  int mode, int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
                                  void *stream, int own_world = 0, int own_rank = 0, const int64_t *local_ids = nullptr,
@@ -489,9 +554,9 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
         MKB_REQUIRE(own_rank >= 0 && own_rank < own_world && (local_ids || n_local_ids == 0) && n_local_ids >= 0, "bad ownership");
         A.own_ids = A.seg_pool; A.own_n = A.filt.P; A.own_world = own_world; A.own_rank = own_rank;
         A.ids = local_ids; A.seg_pool = nullptr;
-        set_row_blocks(A, step_upto > 0 ? (int64_t)A.own_n + n_local_ids : 0);
+        set_row_blocks(A, step_upto > 0 ? (int64_t)A.own_n + n_local_ids : 0, n_rows);
     } else
-    set_row_blocks(A, step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0);  // nothing is pending before the first step
+    set_row_blocks(A, step_upto > 0 ? (int64_t)A.seg_P + 2 * B : 0, n_rows);  // nothing is pending before the first step
     const int64_t rows = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
@@ -521,8 +586,7 @@ extern "C" int mkb_adam_rows_catchup_generate(float *param, float *exp_avg, floa
                                               int64_t n_rows, int64_t D, int64_t step_upto, float beta1, float beta2, float eps,
                                               mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
                                               int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
-    (void)n_rows;
-    return mkb::rows_advance_generate(param, nullptr, exp_avg, exp_avg_sq, last, consts, D, step_upto, 0.f, beta1, beta2, eps,
+    return mkb::rows_advance_generate(param, nullptr, exp_avg, exp_avg_sq, last, consts, n_rows, D, step_upto, 0.f, beta1, beta2, eps,
                                       nullptr, sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream);
 }
 
@@ -557,9 +621,8 @@ extern "C" int mkb_adam_rows_advance_generate(float *param, float *grad, float *
                                               float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *sampler,
                                               const int64_t *sample, int64_t B, int mode, int64_t *neg, int64_t *pool,
                                               int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream) {
-    (void)n_rows;
     MKB_REQUIRE(grad, "null gradient (use mkb_adam_rows_catchup_generate)");
-    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, D, step_upto, lr, beta1, beta2, eps, rider,
+    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, n_rows, D, step_upto, lr, beta1, beta2, eps, rider,
                                       sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream);
 }
 
@@ -572,10 +635,9 @@ extern "C" int mkb_adam_rows_advance_sharded_generate(float *param, float *grad,
                                                       mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode,
                                                       int64_t *neg, int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched,
                                                       void *stream) {
-    (void)n_rows;
     MKB_REQUIRE(world >= 1, "bad world");
     MKB_REQUIRE(grad || !rider, "a dense rider needs the advance form (grad != null)");
-    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, D, step_upto, grad ? lr : 0.f, beta1, beta2,
+    return mkb::rows_advance_generate(param, grad, exp_avg, exp_avg_sq, last, consts, n_rows, D, step_upto, grad ? lr : 0.f, beta1, beta2,
                                       eps, rider, sampler, sample, B, mode, neg, pool, pos, cnt, touched, stream, world, rank,
                                       local_ids, n_local_ids);
 }

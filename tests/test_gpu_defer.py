@@ -86,6 +86,42 @@ def test_deferred_step_equals_separate_step_launch_bit_for_bit(d):
     np.testing.assert_allclose(out[0][3].cpu().numpy(), rel.detach().cpu().numpy(), rtol=0, atol=3e-6)
 
 
+@pytest.mark.parametrize("defer", [True, False])
+def test_sweep_window_of_the_per_step_launch_changes_nothing(defer, monkeypatch):
+    """The per-step optimizer launch may also visit a moving window of table rows (adam.hip, "Sweep": keeps the pending
+    lists short on tables whose entities are rarely touched).  When a row is replayed does not change what is replayed:
+    tables, moments and a mid-run flush are bit-identical for every window period, with and without the deferred step."""
+    from mkb_amd import optim
+
+    out = []
+    for period in ("0", "1", "3", "64", None):  # off, the whole table every step, 1/3 of it, 1/64, the built-in rule
+        if period is None:
+            monkeypatch.delenv("MKB_ADAM_SWEEP", raising=False)
+        else:
+            monkeypatch.setenv("MKB_ADAM_SWEEP", period)
+        ent, rel = _tables(n=20000, d=36)  # 20000 >= 32 x 300 listed rows: the built-in rule sweeps here
+        opt = optim.Adam([ent, rel], lr=1e-2, lazy_rows=True, defer_step=defer)
+        mids = []
+
+        def peek(it):
+            if it == 9:
+                opt.flush()
+                mids.append(ent.detach().clone())
+
+        _synthetic_steps(opt, ent, rel, range(15), on_step=peek)
+        last = opt.state[ent]["last"].clone()
+        opt.flush()
+        st = opt.state[ent]
+        out.append((mids[0], ent.detach().clone(), rel.detach().clone(), st["m"].clone(), st["v"].clone()))
+        if period == "1":  # every row was visited by the last launch: nothing older than the step before the last
+            assert int(last.min()) >= 13
+        if period == "0":
+            assert int(last.min()) <= 10  # (without the window most rows were last visited by the flush after step 9)
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.equal(a, b)
+
+
 def test_deferred_step_survives_set_to_none_and_checkpoint_resume():
     from mkb_amd import optim
 
