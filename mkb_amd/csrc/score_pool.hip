@@ -279,9 +279,12 @@ __global__ __launch_bounds__(256) void rel_fold_kernel(const float *__restrict__
 }
 
 __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restrict__ src, const uint16_t *__restrict__ cnt,
-                                                          float *__restrict__ dst, int64_t n, int64_t P, SeedLayout SL) {
+                                                          float *__restrict__ dst, int64_t n, int64_t n_pad, int64_t P, SeedLayout SL) {
+    // n = B * P entries of the batch; [n, n_pad): the rows that pad the last tile of 8 in the blocked layout, written as 0
+    // (the dense pass of the single-pass backward reads a tile's 8 seeds without looking at B)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[seed_index(SL, i / P, i % P, P)] = cnt[i] ? src[i] : 0.f;
+    else if (i < n_pad) dst[seed_index(SL, i / P, i % P, P)] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -418,6 +421,22 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             while (h2 < halves) h2 *= 2;
             L.pb_halves = h2;
             if (h2 > max_halves || (npb & (npb - 1)) != 0) L.bwd1 = 0;  // (cannot happen: both loops above keep the invariants)
+        }
+        L.dense_lanes = 0;
+        if (L.bwd1) {
+            // Dense pass (pool_bwd1_kernel<..., DENSE>).  Every row takes its first K = P / 2 surviving candidates, so positions
+            // p < K are used by (nearly) every row.  Slot (h, l) holds position block + npb * (l * halves + h): lanes
+            // l < K / (npb * halves) of every half are dense; rounded down to whole lanes per chunk (a chunk = every cph-th lane
+            // of a half).  Built and measured in round 3: the same gradients, the dense positions at 0.8
+            // of the issue floor -- and the launch no faster than the general pass where a phase holds several dense positions
+            // (headline 0.245 vs 0.241 ms per step, YAGO3-10 0.206 vs 0.204), faster where it holds one (WN18RR: 0.144 vs
+            // 0.149: the general pass's per-run stream building weighs most there).  So: on for one dense position per phase,
+            // MKB_POOL_DENSE=1 / 0 forces it on / off (read per call: the tests switch it within one process).
+            const char *e = getenv("MKB_POOL_DENSE");
+            const int cph = 16 / L.pb_halves;
+            const int ld = (int)((P / 2) / ((int64_t)npb * L.pb_halves)) / cph * cph;
+            const bool on = e ? e[0] == '1' : (ld == cph && cp);
+            if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
         if (L.bwd1) {
             const int64_t waves = (int64_t)row_tiles * L.dim_slices * npb;
@@ -690,8 +709,10 @@ extern "C" int mkb_pool_score_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr,
     if (use_mfma(tb)) { ra.cnt = cnt; ra.depth = w.depth; ra.P = (int)(2 * K); }  // used pool depth per row (GEMM cuts)
     if (int rc = dispatch_query_build(tb, mode_is_head(mode), ra, B, st)) return rc;
     // G = caller's gradient with the entries no row uses forced to 0 (the single-pass backward reads the mask off G)
-    hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((B * 2 * K + 255) / 256)), dim3(256), 0, st, dpool_score, cnt, w.G,
-                       B * 2 * K, 2 * K, seed_layout(L));
+    const SeedLayout sl = seed_layout(L);
+    const int64_t n_pad = sl.log2_blocks >= 0 ? (B + 7) / 8 * 8 * 2 * K : B * 2 * K;
+    hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, dpool_score, cnt, w.G,
+                       B * 2 * K, n_pad, 2 * K, sl);
     MKB_LAUNCH_CHECK();
     return pooled_bwd(tb, mode_is_head(mode), gr, sample, pool, cnt, B, 2 * K, w, L, st);
 }

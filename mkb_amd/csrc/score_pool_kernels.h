@@ -33,6 +33,7 @@ namespace mkb {
 constexpr int TI = 8;       // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
 constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions / rows in flight per lane)
 constexpr int kRing1 = 3;   // candidate rows in flight per lane in the single-pass backward
+constexpr int kRingF = 2;   // ... of the fringe's dq half when the dense pass is on (few positions per wave)
 constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8 rows / positions takes the branch-free body
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 2048; // pool positions supported (= the device sampler's limit, size <= 1024)
@@ -57,6 +58,7 @@ struct PoolArgs {
     GemmTail *tile_tail;
     int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
     int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
+    int dense_lanes;             // ... lanes [0, dense_lanes) of every half hold positions of the dense prefix (0 = no dense pass)
     float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
     unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
     DxReduce *dx_reduce_out;     // host side: non-null = do not launch the reduction, describe it here instead
@@ -140,6 +142,11 @@ __device__ __forceinline__ void reduce8_wave(const float (&v)[8], float &t0, flo
     t1 = u[1];
 }
 
+template <int N> struct AccVecOf;
+template <> struct AccVecOf<1> { typedef float type; };
+template <> struct AccVecOf<2> { typedef float2 type; };
+template <> struct AccVecOf<4> { typedef float4 type; };
+
 // Load this lane's KPT consecutive units of a row: UNCONDITIONAL vector load from a clamped offset, then a select.
 // (A predicated load becomes a branch whose join makes the compiler wait for the data immediately, which
 // defeats the prefetch ring.)  KPT > 1 requires the row halves to be KPT*4-byte aligned (host checks).
@@ -163,6 +170,25 @@ __device__ __forceinline__ void load_units(const float *__restrict__ row, int d,
         const float4 b = CP ? *reinterpret_cast<const float4 *>(row + d + uu) : make_float4(0.f, 0.f, 0.f, 0.f);
         d0[0] = ok ? a.x : 0.f; d0[1] = ok ? a.y : 0.f; d0[2] = ok ? a.z : 0.f; d0[3] = ok ? a.w : 0.f;
         d1[0] = ok ? b.x : 0.f; d1[1] = ok ? b.y : 0.f; d1[2] = ok ? b.z : 0.f; d1[3] = ok ? b.w : 0.f;
+    }
+}
+
+// The same load without the select: lanes past the row's end hold data of unit 0 until mask_units() zeroes them.  (Selecting
+// at the load makes the wave wait for the data there and then; the dense pass of the single-pass backward requests a row one
+// position ahead and masks it when it takes it over.)
+template <bool CP, int KPT>
+__device__ __forceinline__ void load_units_raw(const float *__restrict__ row, int d, int NU, int u0, float (&d0)[KPT],
+                                               float (&d1)[KPT]) {
+    const int uu = u0 < NU ? u0 : 0;
+    typedef typename AccVecOf<KPT>::type vec_t;
+    const vec_t a = *reinterpret_cast<const vec_t *>(row + uu);
+    vec_t b = a;
+    if constexpr (CP) b = *reinterpret_cast<const vec_t *>(row + d + uu);
+    if constexpr (KPT == 1) { d0[0] = a; d1[0] = CP ? b : 0.f; }
+    else if constexpr (KPT == 2) { d0[0] = a.x; d0[1] = a.y; d1[0] = CP ? b.x : 0.f; d1[1] = CP ? b.y : 0.f; }
+    else {
+        d0[0] = a.x; d0[1] = a.y; d0[2] = a.z; d0[3] = a.w;
+        d1[0] = CP ? b.x : 0.f; d1[1] = CP ? b.y : 0.f; d1[2] = CP ? b.z : 0.f; d1[3] = CP ? b.w : 0.f;
     }
 }
 
@@ -690,7 +716,7 @@ template <> struct AccVec<1> { typedef float type; };
 template <> struct AccVec<2> { typedef float2 type; };
 template <> struct AccVec<4> { typedef float4 type; };
 
-template <int MODEL, bool HEAD, int KPT>
+template <int MODEL, bool HEAD, int KPT, bool DENSE>  // DENSE: dense pass + chain-free fringe (A.dense_lanes > 0); else the general pass
 __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) {
     constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     constexpr int NC = KPT * (CP ? 2 : 1);  // floats per lane and position
@@ -698,9 +724,17 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     typedef typename AccVec<NC>::type acc_t;
     extern __shared__ __attribute__((aligned(16))) int lds1[];
     const int halves = A.pb_halves, cap = halves * 64;  // halves in {1, 2, 4, 8}
-    acc_t *s_dx = reinterpret_cast<acc_t *>(lds1);                                                       // [cap][64]
-    unsigned long long *s_used = reinterpret_cast<unsigned long long *>(lds1 + (size_t)cap * NC * 64);  // [halves <= 8]
-    int *s_done = lds1 + (size_t)cap * NC * 64 + 16;  // [NW] phases finished by each wave (hand-off chain, see below)
+    // accumulator slots: all of the block's (general pass), or the dense lanes of every half only -- the fringe's dx never
+    // passes through LDS then, and the space holds the waves' candidate-row rings instead
+    const int acc_slots = DENSE ? halves * A.dense_lanes : cap;
+    // DENSE: [128-byte header][accumulator][row images]; behind the dense pass the same space holds the workgroup's 128 query
+    // rows for the fringe's dx half (launch_bwd1 sizes the allocation for the larger of the two uses)
+    constexpr int HDR = DENSE ? 32 : 0;  // (ints)
+    acc_t *s_dx = reinterpret_cast<acc_t *>(lds1 + HDR);                                                            // [acc_slots][64]
+    unsigned long long *s_used = reinterpret_cast<unsigned long long *>(DENSE ? lds1 : lds1 + (size_t)acc_slots * NC * 64);  // [halves <= 8]
+    int *s_done = (DENSE ? lds1 : lds1 + (size_t)acc_slots * NC * 64) + 16;  // [NW] phases finished by each wave (hand-off chain, see below)
+    acc_t *s_x = s_dx + (size_t)acc_slots * 64;  // DENSE: [acc_slots][64] the workgroup's slices of the dense positions' candidate rows
+    acc_t *s_q = s_dx;                           // DENSE, one tile per wave: [16 waves x 8 rows][64] query rows, once the dense pass is over
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (scalar control flow)
@@ -712,12 +746,39 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     // The block's slots are cut into kChunks = 16 chunks, one per wave and phase: chunk c = lanes l == c % cph (mod cph) of half c / cph
     const int cph = kChunks / halves;
     MKB_TRACE_T(tr_t0);
-    MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
+    MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0, tr_dense = 0, tr_pro = 0, tr_p2 = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
 
-    for (int e = tid * 4; e < cap * NC * 64; e += WG * 4)
+    for (int e = tid * 4; e < acc_slots * NC * 64; e += WG * 4)
         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(s_dx) + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < halves) s_used[tid] = 0ull;
     if (tid < NW) s_done[tid] = 0;
+    if constexpr (DENSE) {
+        // the candidate rows of the dense positions, one image per accumulator slot: wave w fills the slots of chunk w
+        // (the chunk it owns in phase 0); the loads of the chunk are issued together
+        const int cph0 = kChunks / halves, lc0 = __builtin_ctz((unsigned)cph0), nd0 = A.dense_lanes >> lc0;
+        const int h0 = wave >> lc0, l0 = wave & (cph0 - 1);
+        for (int k = 0; k < nd0; k += 4) {
+            float xa[4][KPT], xb[4][KPT];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j0 = l0 + (min(k + c, nd0 - 1) << lc0);
+                load_units<CP, KPT>(A.ent + A.pool[pb + A.q_slices * (j0 * halves + h0)] * A.De, A.d, CP ? A.d : (int)A.De,
+                                    (s * 64 + lane) * KPT, xa[c], xb[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (k + c >= nd0) break;
+                const int j0 = l0 + ((k + c) << lc0);
+                acc_t v;
+                if constexpr (NC == 1) v = xa[c][0];
+                else if constexpr (NC == 2 && !CP) { v.x = xa[c][0]; v.y = xa[c][1]; }
+                else if constexpr (NC == 2) { v.x = xa[c][0]; v.y = xb[c][0]; }
+                else if constexpr (NC == 4 && !CP) { v.x = xa[c][0]; v.y = xa[c][1]; v.z = xa[c][KPT - 2]; v.w = xa[c][KPT - 1]; }
+                else { v.x = xa[c][0]; v.y = xa[c][1]; v.z = xb[c][0]; v.w = xb[c][1]; }
+                s_x[(size_t)(h0 * A.dense_lanes + j0) * 64 + lane] = v;
+            }
+        }
+    }
     __syncthreads();
     MKB_TRACE_T(tr_t1);
 
@@ -730,10 +791,15 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
 #pragma unroll
         for (int r = 0; r < TI; ++r) {
-            if (have) load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+            // (all eight rows' loads first, the selects behind them: a select next to its load makes the wave wait there, and the
+            // eight round trips ran one after the other)
+            if (have) load_units_raw<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < TI; ++r) {
 #pragma unroll
             for (int v = 0; v < KPT; ++v) {
-                if (!have || i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+                if (!have || i0 + r >= A.B || u0 >= NU) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
                 dq0[r][v] = 0.f;
                 dq1[r][v] = 0.f;
             }
@@ -752,10 +818,17 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         // tile with the SIMDs running out of ready waves at each (PMC: waves parked 55 % of their lifetime, VALU busy 44 %)
         // -- each wave publishes its finished-phase count in LDS and waits for its ONE predecessor only; the waves fall
         // into a staggered pipeline.  LDS operations of a wave are performed in order, so the count lands after the data.
-        const int g0 = t * kChunks, pred = (wave + 1) & (NW - 1);
+        // A tile takes one or two passes over the 16 chunks: the DENSE pass (lanes [0, dense_lanes) of every half: positions
+        // of the pool's dense prefix, walked without masks or stream order) and the general pass (the other lanes: the sparse
+        // fringe).  The chunk rotation simply continues from one pass into the next.
+        constexpr int n_pass = DENSE ? 2 : 1;
+        const int Ld = (DENSE && have) ? A.dense_lanes : 0;  // (wave-uniform)
+        const int gd0 = t * n_pass * kChunks, g0 = gd0 + (n_pass - 1) * kChunks, pred = (wave + 1) & (NW - 1);
         auto hand_on = [&](int finished) {
-            if (lane == 0) __hip_atomic_store(&s_done[wave], have ? finished : 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!have) return;
+            // (A wave without a row tile walks the chain like the others.  It used to publish "infinitely far ahead", which cuts
+            // the ring open: its successor in the chain is then bounded from below only and may run 15 phases ahead of ITS
+            // successor -- the phase in which the two own the same chunk.)
+            if (lane == 0) __hip_atomic_store(&s_done[wave], finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             MKB_TRACE_ONLY(const unsigned long long th0 = __builtin_readcyclecounter();)
             while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done[pred], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < finished - (kChunkStride - 1))
                 __builtin_amdgcn_s_sleep(1);
@@ -774,6 +847,250 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
             if (finished > behind) __builtin_amdgcn_s_setprio(0);
             else __builtin_amdgcn_s_setprio(3);
         };
+        if constexpr (DENSE) {
+            // Dense pass.  In phase ph the wave owns chunk (wave + ph) mod 16 = lanes l0, l0 + cph, ... of half h; the first
+            // nd = dense_lanes / cph of them are dense positions.  All eight rows take the pair body unconditionally (a row that
+            // does not use the position carries seed 0 and adds exactly 0): straight-line code.
+            //   seeds, pool ids: wave-uniform -> scalar cache (the 8 seeds of a tile are 32 contiguous bytes of the blocked
+            //     layout), issued by hand at the top of a position's body and waited for at its end: left to itself the
+            //     compiler sinks them in front of the s_waitcnt lgkmcnt(0) of the LDS read-modify-write -- a scalar-memory
+            //     round trip per position;
+            //   candidate rows: every wave of the workgroup walks the same 16 x nd positions, so the workgroup's slice of each
+            //     row is brought into LDS ONCE, before the first tile (s_x, filled by the chunk's phase-0 owner), and read
+            //     from there -- per-wave row loads were what the first version of this pass waited for (111 us; without the
+            //     loads 83 us; a 3-deep DMA ring per wave changed nothing: it is the number of requests, not their latency).
+            typedef float v8f __attribute__((ext_vector_type(8)));
+            const int lcph = __builtin_ctz((unsigned)cph), nd = Ld >> lcph;  // (cph = 16 / halves is a power of two)
+            const float *Gt = A.G + (((int64_t)tile * npb + pb) * halves) * 512;
+            v8f gL = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto slot_of = [&](int ph_, int k_, int &p_, int &ds_) {
+                const int c = (kChunkStride * wave + ph_) & (kChunks - 1);
+                const int h_ = c >> lcph, j_ = (c & (cph - 1)) + (k_ << lcph);
+                p_ = pb + npb * (j_ * halves + h_);
+                ds_ = h_ * A.dense_lanes + j_;  // slot of the (dense-only) LDS accumulator
+                return h_ * 64 + j_;            // slot of the block (seed layout, partial buffer)
+            };
+            auto step = [&](int &ph_, int &k_) {  // the position after (ph_, k_); the last one repeats (its loads are harmless)
+                if (k_ + 1 < nd) { ++k_; }
+                else if (ph_ + 1 < kChunks) { ++ph_; k_ = 0; }
+            };
+            auto uni = [](const void *q) {  // the address as a scalar register pair (every lane holds the same value)
+                const unsigned long long v = (unsigned long long)q;
+                return (const void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v));
+            };
+            auto sload_seeds = [&](int slot_) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(gL) : "s"(uni(Gt + slot_ * 8))); };
+            // (the builtin tells the compiler's own wait-count bookkeeping that nothing is outstanding; the asm statement ties
+            // the loaded registers to the wait)
+            auto swait = [&]() {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gL)::"memory");
+            };
+            acc_t xv_n = acc_t{};         // the next position's row image
+            int slot_n = 0, dslot_n = 0;  // the current position's slots
+            int ph1 = 0, k1 = 0;          // the position after the current one (its seeds are requested a position ahead)
+            MKB_TRACE_ONLY(const unsigned long long td0 = __builtin_readcyclecounter(); if (t == 0) tr_pro = td0 - tr_c0;)
+            if (nd > 0) {
+                int p_;
+                slot_n = slot_of(0, 0, p_, dslot_n);
+                sload_seeds(slot_n);
+                xv_n = s_x[(size_t)dslot_n * 64 + lane];
+                swait();
+                step(ph1, k1);
+            }
+            for (int ph = 0; ph < kChunks; ++ph) {
+                for (int k = 0; k < nd; ++k) {
+                    float x0[KPT], x1[KPT], g[TI];
+                    {
+                        const acc_t xv = xv_n;  // (read from LDS a position ago; lanes past the row's end hold 0)
+                        if constexpr (NC == 1) { x0[0] = xv; x1[0] = 0.f; }
+                        else if constexpr (NC == 2 && !CP) { x0[0] = xv.x; x0[1] = xv.y; x1[0] = 0.f; x1[1] = 0.f; }
+                        else if constexpr (NC == 2) { x0[0] = xv.x; x1[0] = xv.y; }
+                        else if constexpr (NC == 4 && !CP) {
+                            x0[0] = xv.x; x0[1] = xv.y; x0[KPT - 2] = xv.z; x0[KPT - 1] = xv.w;
+#pragma unroll
+                            for (int v = 0; v < KPT; ++v) x1[v] = 0.f;
+                        } else { x0[0] = xv.x; x0[1] = xv.y; x1[0] = xv.z; x1[1] = xv.w; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < TI; ++r) g[r] = gL[r];  // (rows past B: their seeds are written as 0 by the producers of G)
+                    acc_t *slot = s_dx + (size_t)dslot_n * 64 + lane;
+                    // requested now, taken over at the end of the body: the seeds of the next position
+                    {
+                        int p_;
+                        slot_n = slot_of(ph1, k1, p_, dslot_n);
+                        sload_seeds(slot_n);
+                        xv_n = s_x[(size_t)dslot_n * 64 + lane];  // the next position's row image (both land under this body's math)
+                        step(ph1, k1);
+                        __builtin_amdgcn_sched_barrier(0);  // (or the scheduler sinks the address arithmetic -- and the load with it -- to the end of the body)
+                    }
+                    float dx0[KPT], dx1[KPT];
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) { dx0[v] = 0.f; dx1[v] = 0.f; }
+                    if constexpr (CP && KPT == 2) {
+#pragma unroll
+                        for (int r = 0; r < TI; r += 2) {
+                            f2 arA = f2{dq0[r][0], dq0[r][1]}, aiA = f2{dq1[r][0], dq1[r][1]};
+                            f2 arB = f2{dq0[r + 1][0], dq0[r + 1][1]}, aiB = f2{dq1[r + 1][0], dq1[r + 1][1]};
+                            f2 br = f2{dx0[0], dx0[1]}, bi = f2{dx1[0], dx1[1]};
+                            pair_bwd_cmod2_both_x2(f2{q0[r][0], q0[r][1]}, f2{q1[r][0], q1[r][1]}, f2{q0[r + 1][0], q0[r + 1][1]},
+                                                   f2{q1[r + 1][0], q1[r + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]}, g[r], g[r + 1],
+                                                   arA, aiA, arB, aiB, br, bi);
+                            dq0[r][0] = arA.x; dq0[r][1] = arA.y; dq1[r][0] = aiA.x; dq1[r][1] = aiA.y;
+                            dq0[r + 1][0] = arB.x; dq0[r + 1][1] = arB.y; dq1[r + 1][0] = aiB.x; dq1[r + 1][1] = aiB.y;
+                            dx0[0] = br.x; dx0[1] = br.y; dx1[0] = bi.x; dx1[1] = bi.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < TI; ++r)
+#pragma unroll
+                            for (int v = 0; v < KPT; ++v) {
+                                if constexpr (CP) {
+                                    Cplx dq, dx;
+                                    pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g[r], dq, dx);
+                                    dq0[r][v] += dq.re; dq1[r][v] += dq.im;
+                                    dx0[v] += dx.re; dx1[v] += dx.im;
+                                } else {
+                                    float dq, dx, e0 = 0.f;
+                                    pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g[r], A.kd, modulus, dq, dx, e0);
+                                    dq0[r][v] += dq;
+                                    dx0[v] += dx;
+                                    extra += g[r] * e0;
+                                }
+                            }
+                    }
+                    acc_t upd = *slot;
+                    if constexpr (NC == 1) upd += dx0[0];
+                    else if constexpr (NC == 2 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; }
+                    else if constexpr (NC == 2) { upd.x += dx0[0]; upd.y += dx1[0]; }
+                    else if constexpr (NC == 4 && !CP) { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx0[2]; upd.w += dx0[3]; }
+                    else { upd.x += dx0[0]; upd.y += dx0[1]; upd.z += dx1[0]; upd.w += dx1[1]; }
+                    *slot = upd;
+                    swait();
+                }
+                hand_on(gd0 + ph + 1);
+            }
+            MKB_TRACE_ONLY(tr_dense += __builtin_readcyclecounter() - td0;)
+        }
+        // With a dense pass the sparse fringe (lanes >= dense_lanes) needs no chain at all: its dq half runs here, row-major, on
+        // registers only (one stream of used fringe positions per half; the dx products of the shared bodies are dead code);
+        // its dx half runs slot-major after the tile loop, every fringe slot owned by ONE wave of the workgroup.  (Sending the
+        // fringe through the chunk rotation cost 88 k of the wave's 243 k cycles at the headline shape for 8 positions per
+        // wave: every phase waited for whichever wave was building a run's stream.)
+        if constexpr (DENSE) {
+            MKB_TRACE_ONLY(const unsigned long long ts0 = __builtin_readcyclecounter();)
+            // (the loads of the next half -- 8 seeds and the pool id of this lane's slot -- fly under the current half's work)
+            float4 ga_n = make_float4(0.f, 0.f, 0.f, 0.f), gb_n = ga_n;
+            int64_t id_nx = 0;
+            auto half_loads = [&](int h_) {
+                if (!have || h_ >= halves) return;
+                const float4 *gp = reinterpret_cast<const float4 *>(A.G + ((((int64_t)tile * npb + pb) * halves + h_) * 64 + lane) * 8);
+                ga_n = gp[0]; gb_n = gp[1];
+                id_nx = A.pool[min(pb + npb * (lane * halves + h_), A.P - 1)];
+            };
+            half_loads(0);
+            for (int h = 0; h < halves; ++h) {
+                float gv[TI];
+                int items = 0, off_lo = 0, off_hi = 0, total = 0;
+                const float4 ga = ga_n, gb = gb_n;
+                const int64_t id_own = id_nx;
+                half_loads(h + 1);
+                if (have) {  // this lane's slot of the half is (h, lane)
+                    const int p_own = pb + npb * (lane * halves + h);
+                    const bool valid = p_own < A.P;
+                    unsigned nz = 0, pm = 0;
+                    gv[0] = ga.x; gv[1] = ga.y; gv[2] = ga.z; gv[3] = ga.w; gv[4] = gb.x; gv[5] = gb.y; gv[6] = gb.z; gv[7] = gb.w;
+#pragma unroll
+                    for (int r = 0; r < TI; ++r) {
+                        gv[r] = (valid && i0 + r < A.B) ? gv[r] : 0.f;
+                        const unsigned u = __float_as_uint(gv[r]) << 1;
+                        nz |= u;
+                        pm |= u ? (0x10000u << (r >> 1)) : 0u;
+                    }
+                    const int64_t off = (valid ? id_own : 0) * A.De;
+                    const bool part = nz != 0 && lane >= Ld;
+                    const unsigned long long used_h = __ballot(nz != 0), pmask = __ballot(part);
+                    if (lane == 0 && used_h) atomicOr(&s_used[h], used_h);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pmask, 0u));
+                    total = __popcll(pmask);
+                    const unsigned long long rest = ~pmask;
+                    const int spare = __builtin_amdgcn_mbcnt_hi((unsigned)(rest >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)rest, 0u));
+                    const int dst = (part ? rank : total + spare) << 2;
+                    items = __builtin_amdgcn_ds_permute(dst, (int)pm);
+                    off_lo = __builtin_amdgcn_ds_permute(dst, (int)(unsigned)off);
+                    off_hi = __builtin_amdgcn_ds_permute(dst, (int)(off >> 32));
+#pragma unroll
+                    for (int r = 0; r < TI; ++r)
+                        gv[r] = __uint_as_float((unsigned)__builtin_amdgcn_ds_permute(dst, (int)__float_as_uint(gv[r])));
+                }
+                auto load_item = [&](int idx, float (&d0)[KPT], float (&d1)[KPT]) {
+                    const int64_t off = ((int64_t)__builtin_amdgcn_readlane(off_hi, idx) << 32) |
+                                        (int64_t)(unsigned)__builtin_amdgcn_readlane(off_lo, idx);
+                    load_units<CP, KPT>(A.ent + off, A.d, NU, u0, d0, d1);
+                };
+                float xr0[kRingF][KPT], xr1[kRingF][KPT];
+                const int last = total - 1;
+                if (total > 0) {
+#pragma unroll
+                    for (int k = 0; k < kRingF; ++k) load_item(min(k, last), xr0[k], xr1[k]);
+                }
+                MKB_TRACE_ONLY(tr_items += total;)
+                for (int it = 0; it < total; it += kRingF) {
+#pragma unroll
+                    for (int k = 0; k < kRingF; ++k) {
+                        const int idx = it + k;
+                        float x0[KPT], x1[KPT];
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) { x0[v] = xr0[k][v]; x1[v] = xr1[k][v]; }
+                        load_item(min(idx + kRingF, last), xr0[k], xr1[k]);
+                        if (idx >= total) continue;
+                        const unsigned word = (unsigned)__builtin_amdgcn_readlane(items, idx);  // row-pair mask << 16
+                        float dx0[KPT], dx1[KPT];  // (never read: the dx products are dead code here)
+#pragma unroll
+                        for (int v = 0; v < KPT; ++v) { dx0[v] = 0.f; dx1[v] = 0.f; }
+#pragma unroll
+                        for (int r = 0; r < TI; r += 2) {
+                            if (!(word & (0x10000u << (r >> 1)))) continue;  // (scalar bit test: neither row of the pair uses the position)
+                            const float gA = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r]), idx));
+                            const float gB = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r + 1]), idx));
+                            if constexpr (CP && KPT == 2) {
+                                f2 arA = f2{dq0[r][0], dq0[r][1]}, aiA = f2{dq1[r][0], dq1[r][1]};
+                                f2 arB = f2{dq0[r + 1][0], dq0[r + 1][1]}, aiB = f2{dq1[r + 1][0], dq1[r + 1][1]};
+                                f2 br = f2{0.f, 0.f}, bi = f2{0.f, 0.f};
+                                pair_bwd_cmod2_both_x2(f2{q0[r][0], q0[r][1]}, f2{q1[r][0], q1[r][1]}, f2{q0[r + 1][0], q0[r + 1][1]},
+                                                       f2{q1[r + 1][0], q1[r + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]}, gA, gB,
+                                                       arA, aiA, arB, aiB, br, bi);
+                                dq0[r][0] = arA.x; dq0[r][1] = arA.y; dq1[r][0] = aiA.x; dq1[r][1] = aiA.y;
+                                dq0[r + 1][0] = arB.x; dq0[r + 1][1] = arB.y; dq1[r + 1][0] = aiB.x; dq1[r + 1][1] = aiB.y;
+                            } else {
+#pragma unroll
+                                for (int rr = r; rr < r + 2; ++rr) {
+                                    const float gr = rr == r ? gA : gB;
+#pragma unroll
+                                    for (int v = 0; v < KPT; ++v) {
+                                        if constexpr (CP) {
+                                            Cplx dq, dx;
+                                            pair_bwd_cmod(Cplx{q0[rr][v], q1[rr][v]}, Cplx{x0[v], x1[v]}, gr, dq, dx);
+                                            dq0[rr][v] += dq.re; dq1[rr][v] += dq.im;
+                                        } else {
+                                            float dq, dx, e0 = 0.f;
+                                            pair_bwd_real<MODEL, HEAD>(q0[rr][v], x0[v], gr, A.kd, modulus, dq, dx, e0);
+                                            dq0[rr][v] += dq;
+                                            extra += gr * e0;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // (the ring's last requests are never consumed: were they still pending -- in the compiler's bookkeeping -- when the
+            // tile loop comes round, it would guard the registers they target with vmcnt waits inside the dense loop, where
+            // they drain the DMA ring it cannot see)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            MKB_TRACE_ONLY(tr_setup += __builtin_readcyclecounter() - ts0;)
+        } else
         // The 16 phases of a tile split into RUNS of consecutive phases whose chunks lie in the same half (the seeds and ids
         // of one half fit the lanes).  Inside a run the wave's used positions form one stream, ordered by phase: everything
         // the loop needs per position is PERMUTED INTO STREAM ORDER once per run (lane i = i-th position: its slot, phase,
@@ -808,7 +1125,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 }
                 const int64_t off = (valid ? A.pool[p_own] : 0) * A.De;
                 const int rp = (lane % cph) - l00;  // phase of this lane's chunk, relative to the run
-                const bool part = nz != 0 && rp >= 0 && rp < len;
+                const bool part = nz != 0 && rp >= 0 && rp < len && lane >= Ld;  // (dense lanes were done by the dense pass)
                 const unsigned long long used_h = __ballot(nz != 0), pmask = __ballot(part);
                 if (lane == 0 && used_h) atomicOr(&s_used[h], used_h);
                 // stream rank of this lane's position: positions of earlier phases + earlier lanes of the same chunk
@@ -943,12 +1260,187 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 if (lane == 0) atomicAdd(A.g_modulus, -extra);
             }
         }
+        if constexpr (DENSE) {
+            if (A.tiles_per_wave == 1) {  // (workgroup-uniform; every wave runs the tile loop exactly once)
+                // The fringe's dx half (below) walks, per fringe slot, the rows of the WORKGROUP that use it.  Fetched from the
+                // Q buffer those rows were what that part waited for (16 scattered 1 KB requests per batch: 47-64 k cycles on the
+                // wave with the heaviest slot); the rows are in registers right here, and LDS is free once the accumulator has
+                // been flushed: flush, then park the tile's eight rows for the slot owners.
+                __syncthreads();  // every wave's dense pass is over
+                {
+                    const size_t wg = (size_t)rg * npb + pb;
+                    acc_t *out = reinterpret_cast<acc_t *>(A.dXp) + ((wg * cap) * A.dim_slices + s) * 64 + lane;
+                    for (int sidx = wave; sidx < cap; sidx += NW) {
+                        if ((sidx & 63) >= A.dense_lanes || !((s_used[sidx >> 6] >> (sidx & 63)) & 1ull)) continue;
+                        out[(size_t)sidx * A.dim_slices * 64] = s_dx[(size_t)((sidx >> 6) * A.dense_lanes + (sidx & 63)) * 64 + lane];
+                    }
+                }
+                __syncthreads();  // the accumulator has been read out
+#pragma unroll
+                for (int r = 0; r < TI; ++r) {
+                    acc_t v;
+                    if constexpr (NC == 1) v = q0[r][0];
+                    else if constexpr (NC == 2 && !CP) { v.x = q0[r][0]; v.y = q0[r][1]; }
+                    else if constexpr (NC == 2) { v.x = q0[r][0]; v.y = q1[r][0]; }
+                    else if constexpr (NC == 4 && !CP) { v.x = q0[r][0]; v.y = q0[r][1]; v.z = q0[r][KPT - 2]; v.w = q0[r][KPT - 1]; }
+                    else { v.x = q0[r][0]; v.y = q0[r][1]; v.z = q1[r][0]; v.w = q1[r][1]; }
+                    s_q[(size_t)(wave * TI + r) * 64 + lane] = v;  // (a wave without a tile parks zeros)
+                }
+            }
+        }
+    }
+    if constexpr (DENSE) {
+        // dx of the fringe, slot-major.  The used-slot masks are complete once every wave has left its tile loop (barrier);
+        // the used fringe slots are dealt round-robin to the 16 waves (in pool order: the rows per slot fall with the position,
+        // so the deal is balanced).  The owner walks the rows of the workgroup that use the slot -- the seeds of 128 rows are 8
+        // bytes per lane of the blocked layout -- sixteen rows at a time (their query rows come from the Q buffer: 32 loads in
+        // flight), sums their dx in registers in a fixed order and STORES the slot's partial: nobody else touches it.  This
+        // part is all latency, so everything a wave's slots need first (seeds, pool ids, then candidate rows) is requested
+        // for up to four slots at once.
+        __syncthreads();
+        MKB_TRACE_ONLY(const unsigned long long tf0 = __builtin_readcyclecounter();)
+        constexpr int NB = 16;
+        const int row_tiles2 = (A.B + TI - 1) / TI;
+        const unsigned long long fmask = A.dense_lanes >= 64 ? 0ull : ~0ull << A.dense_lanes;
+        int n_used = 0;
+        for (int h = 0; h < halves; ++h) n_used += __popcll(s_used[h] & fmask);
+        n_used = __builtin_amdgcn_readfirstlane(n_used);
+        auto nth_slot = [&](int r, int &h_, int &j_) {  // the r-th used fringe slot in pool order (r < n_used)
+            for (int h = 0; h < halves; ++h) {
+                unsigned long long bits = s_used[h] & fmask;
+                bits = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) |
+                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+                const int c = __popcll(bits);
+                if (r >= c) { r -= c; continue; }
+                for (; r > 0; --r) bits &= bits - 1ull;
+                h_ = h; j_ = (int)__builtin_ctzll(bits);
+                return;
+            }
+            h_ = 0; j_ = 0;
+        };
+        // this wave's slots: ranks wave, wave + 16, ...; the seeds (of the first 128 rows) and the pool id of the NEXT slot are
+        // requested while the current one is worked on, its candidate row as soon as the id is in
+        const int tile_l0 = rg * A.tiles_per_wave * NW + (lane >> 2);
+        float n_gsx = 0.f, n_gsy = 0.f, nx0[KPT], nx1[KPT];
+        int n_h = 0, n_j = 0;
+        int64_t n_id = 0;
+        auto request = [&](int r) {  // seeds and pool id of slot rank r (nothing is waited for here)
+            if (r >= n_used) return;
+            nth_slot(r, n_h, n_j);
+            n_id = A.pool[pb + npb * (n_j * halves + n_h)];
+            n_gsx = 0.f; n_gsy = 0.f;
+            if (tile_l0 < row_tiles2) {
+                const float2 gs = *reinterpret_cast<const float2 *>(A.G + ((((int64_t)tile_l0 * npb + pb) * halves + n_h) * 64 + n_j) * 8 + (lane & 3) * 2);
+                n_gsx = gs.x; n_gsy = gs.y;
+            }
+        };
+        auto request_row = [&](int r) {  // ... its candidate row, once the id is in (lanes past the row's end: never read back)
+            if (r < n_used) load_units_raw<CP, KPT>(A.ent + n_id * A.De, A.d, NU, u0, nx0, nx1);
+        };
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) { nx0[v] = 0.f; nx1[v] = 0.f; }
+        request(wave);
+        request_row(wave);
+        for (int r = wave; r < n_used; r += NW) {
+            const int j = n_j, h = n_h;
+            float x0[KPT], x1[KPT], dx0[KPT], dx1[KPT];
+            const float gsx = n_gsx, gsy = n_gsy;
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { x0[v] = nx0[v]; x1[v] = nx1[v]; dx0[v] = 0.f; dx1[v] = 0.f; }
+            request(r + NW);
+            for (int t2 = 0; t2 < A.tiles_per_wave; ++t2) {
+                const int tile_b = (rg * A.tiles_per_wave + t2) * NW;  // 16 tiles = 128 rows; lane -> rows 2 * lane, 2 * lane + 1 of them
+                const int tile_l = tile_b + (lane >> 2), ib = tile_b * TI;
+                float vx = gsx, vy = gsy;
+                if (t2 > 0) {
+                    vx = 0.f; vy = 0.f;
+                    if (tile_l < row_tiles2) {
+                        const float2 gs = *reinterpret_cast<const float2 *>(A.G + ((((int64_t)tile_l * npb + pb) * halves + h) * 64 + j) * 8 + (lane & 3) * 2);
+                        vx = gs.x; vy = gs.y;
+                    }
+                }
+                vx = ib + 2 * lane < A.B ? vx : 0.f;
+                vy = ib + 2 * lane + 1 < A.B ? vy : 0.f;
+                // rows in a fixed order: the even rows of the 128 (lane order), then the odd ones
+                unsigned long long m0 = __ballot((__float_as_uint(vx) << 1) != 0u), m1 = __ballot((__float_as_uint(vy) << 1) != 0u);
+                while (m0 | m1) {
+                    float gr[NB], qa0[NB][KPT], qa1[NB][KPT];
+                    int li[NB];  // row of the 128 (2 * lane + odd)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {  // the next sixteen rows (short of sixteen: row 0 with seed 0)
+                        const bool odd = m0 == 0ull;
+                        const unsigned long long mm = odd ? m1 : m0;
+                        const bool ok = mm != 0ull;
+                        const int L = ok ? (int)__builtin_ctzll(mm) : 0;
+                        const float ge = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vx), L));
+                        const float go = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vy), L));
+                        gr[c] = ok ? (odd ? go : ge) : 0.f;
+                        m1 = odd ? (m1 & (m1 - 1ull)) : m1;  // (x & (x - 1) of 0 is 0)
+                        m0 = odd ? m0 : (m0 & (m0 - 1ull));
+                        li[c] = 2 * L + (odd ? 1 : 0);
+                    }
+                    if (A.tiles_per_wave == 1) {  // parked in LDS by the rows' owners: sixteen reads in flight
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) {
+                            const acc_t qv = s_q[(size_t)li[c] * 64 + lane];
+                            if constexpr (NC == 1) { qa0[c][0] = qv; qa1[c][0] = 0.f; }
+                            else if constexpr (NC == 2 && !CP) { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = 0.f; qa1[c][1] = 0.f; }
+                            else if constexpr (NC == 2) { qa0[c][0] = qv.x; qa1[c][0] = qv.y; }
+                            else if constexpr (NC == 4 && !CP) {
+                                qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa0[c][KPT - 2] = qv.z; qa0[c][KPT - 1] = qv.w;
+#pragma unroll
+                                for (int v = 0; v < KPT; ++v) qa1[c][v] = 0.f;
+                            } else { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = qv.z; qa1[c][1] = qv.w; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NB; ++c)
+                            load_units_raw<CP, KPT>(A.Q + (int64_t)min(ib + li[c], A.B - 1) * A.De, A.d, NU, u0, qa0[c], qa1[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NB; c += 2) {
+                        if constexpr (CP && KPT == 2) {
+                            f2 arA = f2{0.f, 0.f}, aiA = arA, arB = arA, aiB = arA;  // (the dq products are dead code here)
+                            f2 br = f2{dx0[0], dx0[1]}, bi = f2{dx1[0], dx1[1]};
+                            pair_bwd_cmod2_both_x2(f2{qa0[c][0], qa0[c][1]}, f2{qa1[c][0], qa1[c][1]}, f2{qa0[c + 1][0], qa0[c + 1][1]},
+                                                   f2{qa1[c + 1][0], qa1[c + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]},
+                                                   gr[c], gr[c + 1], arA, aiA, arB, aiB, br, bi);
+                            dx0[0] = br.x; dx0[1] = br.y; dx1[0] = bi.x; dx1[1] = bi.y;
+                        } else {
+#pragma unroll
+                            for (int cc = c; cc < c + 2; ++cc)
+#pragma unroll
+                                for (int v = 0; v < KPT; ++v) {
+                                    if constexpr (CP) {
+                                        Cplx dq, dx;
+                                        pair_bwd_cmod(Cplx{qa0[cc][v], qa1[cc][v]}, Cplx{x0[v], x1[v]}, gr[cc], dq, dx);
+                                        dx0[v] += dx.re; dx1[v] += dx.im;
+                                    } else {
+                                        float dq, dx, e0 = 0.f;
+                                        pair_bwd_real<MODEL, HEAD>(qa0[cc][v], x0[v], gr[cc], A.kd, modulus, dq, dx, e0);
+                                        dx0[v] += dx;
+                                    }
+                                }
+                        }
+                    }
+                }
+            }
+            request_row(r + NW);
+            acc_t upd;
+            if constexpr (NC == 1) upd = dx0[0];
+            else if constexpr (NC == 2 && !CP) { upd.x = dx0[0]; upd.y = dx0[1]; }
+            else if constexpr (NC == 2) { upd.x = dx0[0]; upd.y = dx1[0]; }
+            else if constexpr (NC == 4 && !CP) { upd.x = dx0[0]; upd.y = dx0[1]; upd.z = dx0[2]; upd.w = dx0[3]; }
+            else { upd.x = dx0[0]; upd.y = dx0[1]; upd.z = dx1[0]; upd.w = dx1[1]; }
+            reinterpret_cast<acc_t *>(A.dXp)[((((size_t)rg * npb + pb) * cap + (h * 64 + j)) * A.dim_slices + s) * 64 + lane] = upd;
+        }
+        MKB_TRACE_ONLY(tr_p2 += __builtin_readcyclecounter() - tf0;)
     }
     MKB_TRACE_T(tr_t2);
 #ifdef MKB_TRACE_WG
     if (lane == 0 && A.trace && A.trace_kind == 4) {  // per-wave record (tools/wgtrace.py run bwd1): cycles
         unsigned long long *tr = A.trace + 8ull * ((unsigned long long)blockIdx.x * NW + wave);
-        tr[0] = __builtin_readcyclecounter() - tr_c0; tr[1] = tr_hand; tr[2] = tr_setup; tr[3] = 1; tr[4] = tr_items; tr[5] = wave; tr[6] = 0; tr[7] = blockIdx.x;
+        tr[0] = __builtin_readcyclecounter() - tr_c0; tr[1] = tr_hand; tr[2] = tr_setup; tr[3] = 1; tr[4] = tr_items | (tr_pro << 16); tr[5] = wave; tr[6] = tr_dense; tr[7] = tr_p2;
     }
 #endif
     __syncthreads();  // every wave's last phase is done
@@ -962,7 +1454,12 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         acc_t *out = reinterpret_cast<acc_t *>(A.dXp) + ((wg * cap) * A.dim_slices + s) * 64 + lane;
         for (int sidx = wave; sidx < cap; sidx += NW) {
             if (!((s_used[sidx >> 6] >> (sidx & 63)) & 1ull)) continue;
-            out[(size_t)sidx * A.dim_slices * 64] = s_dx[(size_t)sidx * 64 + lane];
+            if constexpr (DENSE) {  // (the fringe slots went straight to the buffer; with one tile per wave the dense ones as well)
+                if ((sidx & 63) >= A.dense_lanes || A.tiles_per_wave == 1) continue;
+                out[(size_t)sidx * A.dim_slices * 64] = s_dx[(size_t)((sidx >> 6) * A.dense_lanes + (sidx & 63)) * 64 + lane];
+            } else {
+                out[(size_t)sidx * A.dim_slices * 64] = s_dx[(size_t)sidx * 64 + lane];
+            }
         }
     }
     MKB_TRACE_OUT(A, 1, tr_t0, tr_t1, tr_t2, 0);
@@ -1048,6 +1545,7 @@ struct PoolLaunch {
     int bwd1;             // single-pass backward (pool_bwd1_kernel): q_slices = position blocks, plus the five below
     int bkpt;             // its units per lane (1, 2, or 4 for real-valued models with long rows)
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
+    int dense_lanes;      // lanes of every half that hold dense-prefix positions (pool_bwd1_kernel's dense pass; 0 = none)
     int tile, tile_kd, tile_ks, tile_fringe_slices;  // forward: dense prefix [0, tile_kd) on the register tile (score_pool_tile.h)
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
@@ -1091,19 +1589,30 @@ static int launch_cfg(int which, const PoolLaunch &L, const PoolArgs &A, hipStre
 template <int MODEL, bool HEAD, int KPT>
 static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     constexpr int NC = KPT * (ModelTraits<MODEL>::cplx_pair ? 2 : 1);
-    const size_t lds = (size_t)L.pb_halves * 64 * NC * 64 * 4 + 128;
-    static size_t lds_ok = 0;  // per instantiation: opt in to more than 64 KB of dynamic LDS once
-    if (lds > 64 * 1024 && lds > lds_ok) {
-        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_ok = 160 * 1024;
-    }
+    const bool dense_cfg = A.g_blocked && L.dense_lanes > 0;
+    const size_t lds_pass = (size_t)2 * L.pb_halves * L.dense_lanes * NC * 64 * 4;  // accumulator + row images of the dense slots
+    const size_t lds_rows = L.tiles_per_wave == 1 ? (size_t)kBwd1Waves * TI * NC * 64 * 4 : 0;  // ... then the workgroup's query rows
+    const size_t lds = dense_cfg ? (lds_pass > lds_rows ? lds_pass : lds_rows) + 128
+                                 : (size_t)L.pb_halves * 64 * NC * 64 * 4 + 128;
     PoolArgs A2 = A;
     A2.q_slices = L.q_slices; A2.dim_slices = L.dim_slices; A2.pb_halves = L.pb_halves; A2.tiles_per_wave = L.tiles_per_wave;
+    A2.dense_lanes = A.g_blocked ? L.dense_lanes : 0;  // (the dense pass reads the blocked seed layout)
+    const bool dense = A2.dense_lanes > 0;
+    static size_t lds_ok[2] = {0, 0};  // per instantiation: opt in to more than 64 KB of dynamic LDS once
+    if (lds > 64 * 1024 && lds > lds_ok[dense]) {
+        const void *fn = dense ? reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, true>)
+                               : reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, false>);
+        MKB_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_ok[dense] = 160 * 1024;
+    }
     const int row_tiles = (A.B + TI - 1) / TI, per_group = kBwd1Waves * L.tiles_per_wave;
     const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);
-    hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT>), dim3(groups * L.q_slices * L.dim_slices),
-                       dim3(kBwd1Waves * 64), lds, st, A2);
+    if (dense)
+        hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT, true>), dim3(groups * L.q_slices * L.dim_slices),
+                           dim3(kBwd1Waves * 64), lds, st, A2);
+    else
+        hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT, false>), dim3(groups * L.q_slices * L.dim_slices),
+                           dim3(kBwd1Waves * 64), lds, st, A2);
     const DxReduce R = make_dx_reduce(A2, KPT, ModelTraits<MODEL>::cplx_pair, (int)groups);
     if (A.dx_reduce_out) *A.dx_reduce_out = R;  // the caller's next launch (row backward) carries the reduction
     else hipLaunchKernelGGL(pool_dx_reduce_kernel<0>, dim3((unsigned)R.blocks), dim3(256), 0, st, R);

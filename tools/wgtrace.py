@@ -51,9 +51,12 @@ def run(kind="bwd_x", step=10):
         print(f"waves {len(t)}  loop cycles mean {t[:, 0].mean():.0f} (min {t[:, 0].min():.0f} max {t[:, 0].max():.0f})  "
               f"hand-off wait mean {t[:, 1].mean():.0f} max {t[:, 1].max():.0f}  run setup mean {t[:, 2].mean():.0f}  "
               f"positions per wave mean {t[:, 4].mean():.1f} max {t[:, 4].max():.0f}")
+        pro = np.floor(t[:, 4] / 65536.0)
+        t[:, 4] = t[:, 4] - pro * 65536.0
+        print(f"prologue (entry -> first dense pass) mean {pro.mean():.0f}  fringe dx part mean {t[:, 7].mean():.0f} max {t[:, 7].max():.0f}  dense pass mean {t[:, 6].mean():.0f}")
         for w in range(16):
             m = t[:, 5] == w
-            print(f"  wave {w:2d}: loop {t[m, 0].mean():8.0f}  hand-off {t[m, 1].mean():8.0f}  setup {t[m, 2].mean():7.0f}  items {t[m, 4].mean():5.1f}")
+            print(f"  wave {w:2d}: loop {t[m, 0].mean():8.0f}  hand-off {t[m, 1].mean():8.0f}  setup {t[m, 2].mean():7.0f}  items {t[m, 4].mean():5.1f}  dense {t[m, 6].mean():8.0f}")
         return
     if kind == "all":  # the three kernels of one step on one clock: where does the time between them go?
         raw = buf.cpu().numpy().reshape(3, 4096, 8)
