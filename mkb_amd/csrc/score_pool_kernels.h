@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     // The block's slots are cut into kChunks = 16 chunks, one per wave and phase: chunk c = lanes l == c % cph (mod cph) of half c / cph
     const int cph = kChunks / halves;
     MKB_TRACE_T(tr_t0);
-    MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0, tr_dense = 0, tr_pro = 0, tr_p2 = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
+    MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0, tr_dense = 0, tr_pro = 0, tr_p2 = 0, tr_p2rows = 0, tr_p2slots = 0, tr_p2batch = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
 
     for (int e = tid * 4; e < acc_slots * NC * 64; e += WG * 4)
         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(s_dx) + e) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1339,15 +1339,25 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         };
 #pragma unroll
         for (int v = 0; v < KPT; ++v) { nx0[v] = 0.f; nx1[v] = 0.f; }
-        request(wave);
-        request_row(wave);
-        for (int r = wave; r < n_used; r += NW) {
+        // the deal goes back and forth (ranks w, 31 - w, 32 + w, ...): the rows per slot fall with the rank, so the wave with
+        // the heaviest slot of one round gets the lightest of the next
+        auto rank_of = [&](int k) { return k * NW + ((k & 1) ? NW - 1 - wave : wave); };
+        request(rank_of(0));
+        request_row(rank_of(0));
+        for (int k = 0, r = rank_of(0); k * NW < n_used; ++k, r = rank_of(k)) {
+            if (r >= n_used) continue;  // (only in the last round; nothing was requested for it)
+            const int r_next = (k + 1) * NW < n_used ? rank_of(k + 1) : n_used;
             const int j = n_j, h = n_h;
             float x0[KPT], x1[KPT], dx0[KPT], dx1[KPT];
             const float gsx = n_gsx, gsy = n_gsy;
 #pragma unroll
             for (int v = 0; v < KPT; ++v) { x0[v] = nx0[v]; x1[v] = nx1[v]; dx0[v] = 0.f; dx1[v] = 0.f; }
-            request(r + NW);
+            float ax0[4][KPT], ax1[4][KPT];
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4)
+#pragma unroll
+                for (int v = 0; v < KPT; ++v) { ax0[a4][v] = 0.f; ax1[a4][v] = 0.f; }
+            request(r_next);
             for (int t2 = 0; t2 < A.tiles_per_wave; ++t2) {
                 const int tile_b = (rg * A.tiles_per_wave + t2) * NW;  // 16 tiles = 128 rows; lane -> rows 2 * lane, 2 * lane + 1 of them
                 const int tile_l = tile_b + (lane >> 2), ib = tile_b * TI;
@@ -1361,71 +1371,83 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 }
                 vx = ib + 2 * lane < A.B ? vx : 0.f;
                 vy = ib + 2 * lane + 1 < A.B ? vy : 0.f;
-                // rows in a fixed order: the even rows of the 128 (lane order), then the odd ones
-                unsigned long long m0 = __ballot((__float_as_uint(vx) << 1) != 0u), m1 = __ballot((__float_as_uint(vy) << 1) != 0u);
-                while (m0 | m1) {
-                    float gr[NB], qa0[NB][KPT], qa1[NB][KPT];
-                    int li[NB];  // row of the 128 (2 * lane + odd)
+                // rows in a fixed order: the even rows of the 128 (lane order), then the odd ones; sixteen rows per batch, their
+                // dx products on FOUR accumulators that take turns (one accumulator chains all the bodies of a batch: a lone
+                // wave -- few waves have a heavy slot -- then runs at the latency of every packed op) and are added up in a fixed
+                // order at the end
+                const unsigned long long me = __ballot((__float_as_uint(vx) << 1) != 0u), mo = __ballot((__float_as_uint(vy) << 1) != 0u);
+                MKB_TRACE_ONLY(tr_p2rows += __popcll(me) + __popcll(mo); tr_p2slots += 1; const unsigned long long tb0 = __builtin_readcyclecounter();)
+                for (int pass = 0; pass < 2; ++pass) {
+                    unsigned long long m = pass ? mo : me;  // (wave-uniform)
+                    const float vv = pass ? vy : vx;
+                    while (m) {
+                        float gr[NB], qa0[NB][KPT], qa1[NB][KPT];
+                        int li[NB];  // row of the 128 (2 * lane + pass)
 #pragma unroll
-                    for (int c = 0; c < NB; ++c) {  // the next sixteen rows (short of sixteen: row 0 with seed 0)
-                        const bool odd = m0 == 0ull;
-                        const unsigned long long mm = odd ? m1 : m0;
-                        const bool ok = mm != 0ull;
-                        const int L = ok ? (int)__builtin_ctzll(mm) : 0;
-                        const float ge = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vx), L));
-                        const float go = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vy), L));
-                        gr[c] = ok ? (odd ? go : ge) : 0.f;
-                        m1 = odd ? (m1 & (m1 - 1ull)) : m1;  // (x & (x - 1) of 0 is 0)
-                        m0 = odd ? m0 : (m0 & (m0 - 1ull));
-                        li[c] = 2 * L + (odd ? 1 : 0);
-                    }
-                    if (A.tiles_per_wave == 1) {  // parked in LDS by the rows' owners: sixteen reads in flight
-#pragma unroll
-                        for (int c = 0; c < NB; ++c) {
-                            const acc_t qv = s_q[(size_t)li[c] * 64 + lane];
-                            if constexpr (NC == 1) { qa0[c][0] = qv; qa1[c][0] = 0.f; }
-                            else if constexpr (NC == 2 && !CP) { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = 0.f; qa1[c][1] = 0.f; }
-                            else if constexpr (NC == 2) { qa0[c][0] = qv.x; qa1[c][0] = qv.y; }
-                            else if constexpr (NC == 4 && !CP) {
-                                qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa0[c][KPT - 2] = qv.z; qa0[c][KPT - 1] = qv.w;
-#pragma unroll
-                                for (int v = 0; v < KPT; ++v) qa1[c][v] = 0.f;
-                            } else { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = qv.z; qa1[c][1] = qv.w; }
+                        for (int c = 0; c < NB; ++c) {  // the next sixteen rows (short of sixteen: row 0 with seed 0)
+                            const bool ok = m != 0ull;
+                            const int L = ok ? (int)__builtin_ctzll(m) : 0;
+                            const float gl = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(vv), L));
+                            gr[c] = ok ? gl : 0.f;
+                            m &= m - 1ull;  // (x & (x - 1) of 0 is 0)
+                            li[c] = 2 * L + pass;
                         }
-                    } else {
+                        if (A.tiles_per_wave == 1) {  // parked in LDS by the rows' owners: sixteen reads in flight
 #pragma unroll
-                        for (int c = 0; c < NB; ++c)
-                            load_units_raw<CP, KPT>(A.Q + (int64_t)min(ib + li[c], A.B - 1) * A.De, A.d, NU, u0, qa0[c], qa1[c]);
-                    }
+                            for (int c = 0; c < NB; ++c) {
+                                const acc_t qv = s_q[(size_t)li[c] * 64 + lane];
+                                if constexpr (NC == 1) { qa0[c][0] = qv; qa1[c][0] = 0.f; }
+                                else if constexpr (NC == 2 && !CP) { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = 0.f; qa1[c][1] = 0.f; }
+                                else if constexpr (NC == 2) { qa0[c][0] = qv.x; qa1[c][0] = qv.y; }
+                                else if constexpr (NC == 4 && !CP) {
+                                    qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa0[c][KPT - 2] = qv.z; qa0[c][KPT - 1] = qv.w;
 #pragma unroll
-                    for (int c = 0; c < NB; c += 2) {
-                        if constexpr (CP && KPT == 2) {
-                            f2 arA = f2{0.f, 0.f}, aiA = arA, arB = arA, aiB = arA;  // (the dq products are dead code here)
-                            f2 br = f2{dx0[0], dx0[1]}, bi = f2{dx1[0], dx1[1]};
-                            pair_bwd_cmod2_both_x2(f2{qa0[c][0], qa0[c][1]}, f2{qa1[c][0], qa1[c][1]}, f2{qa0[c + 1][0], qa0[c + 1][1]},
-                                                   f2{qa1[c + 1][0], qa1[c + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]},
-                                                   gr[c], gr[c + 1], arA, aiA, arB, aiB, br, bi);
-                            dx0[0] = br.x; dx0[1] = br.y; dx1[0] = bi.x; dx1[1] = bi.y;
+                                    for (int v = 0; v < KPT; ++v) qa1[c][v] = 0.f;
+                                } else { qa0[c][0] = qv.x; qa0[c][1] = qv.y; qa1[c][0] = qv.z; qa1[c][1] = qv.w; }
+                            }
                         } else {
 #pragma unroll
-                            for (int cc = c; cc < c + 2; ++cc)
+                            for (int c = 0; c < NB; ++c)
+                                load_units_raw<CP, KPT>(A.Q + (int64_t)min(ib + li[c], A.B - 1) * A.De, A.d, NU, u0, qa0[c], qa1[c]);
+                        }
 #pragma unroll
-                                for (int v = 0; v < KPT; ++v) {
-                                    if constexpr (CP) {
-                                        Cplx dq, dx;
-                                        pair_bwd_cmod(Cplx{qa0[cc][v], qa1[cc][v]}, Cplx{x0[v], x1[v]}, gr[cc], dq, dx);
-                                        dx0[v] += dx.re; dx1[v] += dx.im;
-                                    } else {
-                                        float dq, dx, e0 = 0.f;
-                                        pair_bwd_real<MODEL, HEAD>(qa0[cc][v], x0[v], gr[cc], A.kd, modulus, dq, dx, e0);
-                                        dx0[v] += dx;
+                        for (int c = 0; c < NB; c += 2) {
+                            constexpr int NA = 4;
+                            const int a4 = (c >> 1) & (NA - 1);
+                            if constexpr (CP && KPT == 2) {
+                                f2 arA = f2{0.f, 0.f}, aiA = arA, arB = arA, aiB = arA;  // (the dq products are dead code here)
+                                f2 br = f2{ax0[a4][0], ax0[a4][1]}, bi = f2{ax1[a4][0], ax1[a4][1]};
+                                pair_bwd_cmod2_both_x2(f2{qa0[c][0], qa0[c][1]}, f2{qa1[c][0], qa1[c][1]}, f2{qa0[c + 1][0], qa0[c + 1][1]},
+                                                       f2{qa1[c + 1][0], qa1[c + 1][1]}, f2{x0[0], x0[1]}, f2{x1[0], x1[1]},
+                                                       gr[c], gr[c + 1], arA, aiA, arB, aiB, br, bi);
+                                ax0[a4][0] = br.x; ax0[a4][1] = br.y; ax1[a4][0] = bi.x; ax1[a4][1] = bi.y;
+                            } else {
+#pragma unroll
+                                for (int cc = c; cc < c + 2; ++cc)
+#pragma unroll
+                                    for (int v = 0; v < KPT; ++v) {
+                                        if constexpr (CP) {
+                                            Cplx dq, dx;
+                                            pair_bwd_cmod(Cplx{qa0[cc][v], qa1[cc][v]}, Cplx{x0[v], x1[v]}, gr[cc], dq, dx);
+                                            ax0[a4][v] += dx.re; ax1[a4][v] += dx.im;
+                                        } else {
+                                            float dq, dx, e0 = 0.f;
+                                            pair_bwd_real<MODEL, HEAD>(qa0[cc][v], x0[v], gr[cc], A.kd, modulus, dq, dx, e0);
+                                            ax0[a4][v] += dx;
+                                        }
                                     }
-                                }
+                            }
                         }
                     }
                 }
+                MKB_TRACE_ONLY(tr_p2batch += __builtin_readcyclecounter() - tb0;)
             }
-            request_row(r + NW);
+            request_row(r_next);
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) {
+                dx0[v] = (ax0[0][v] + ax0[1][v]) + (ax0[2][v] + ax0[3][v]);
+                dx1[v] = (ax1[0][v] + ax1[1][v]) + (ax1[2][v] + ax1[3][v]);
+            }
             acc_t upd;
             if constexpr (NC == 1) upd = dx0[0];
             else if constexpr (NC == 2 && !CP) { upd.x = dx0[0]; upd.y = dx0[1]; }
@@ -1440,7 +1462,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
 #ifdef MKB_TRACE_WG
     if (lane == 0 && A.trace && A.trace_kind == 4) {  // per-wave record (tools/wgtrace.py run bwd1): cycles
         unsigned long long *tr = A.trace + 8ull * ((unsigned long long)blockIdx.x * NW + wave);
-        tr[0] = __builtin_readcyclecounter() - tr_c0; tr[1] = tr_hand; tr[2] = tr_setup; tr[3] = 1; tr[4] = tr_items | (tr_pro << 16); tr[5] = wave; tr[6] = tr_dense; tr[7] = tr_p2;
+        tr[0] = __builtin_readcyclecounter() - tr_c0; tr[1] = tr_hand; tr[2] = tr_setup; tr[3] = 1 | (tr_p2slots << 1) | (tr_p2rows << 8) | (tr_p2batch << 24); tr[4] = tr_items | (tr_pro << 16); tr[5] = wave; tr[6] = tr_dense; tr[7] = tr_p2;
     }
 #endif
     __syncthreads();  // every wave's last phase is done

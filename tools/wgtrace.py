@@ -51,6 +51,12 @@ def run(kind="bwd_x", step=10):
         print(f"waves {len(t)}  loop cycles mean {t[:, 0].mean():.0f} (min {t[:, 0].min():.0f} max {t[:, 0].max():.0f})  "
               f"hand-off wait mean {t[:, 1].mean():.0f} max {t[:, 1].max():.0f}  run setup mean {t[:, 2].mean():.0f}  "
               f"positions per wave mean {t[:, 4].mean():.1f} max {t[:, 4].max():.0f}")
+        w3 = t[:, 3].astype(np.int64)
+        p2_slots, p2_rows, p2_batch = (w3 >> 1) & 127, (w3 >> 8) & 65535, w3 >> 24
+        print(f"fringe dx half per wave: slots mean {p2_slots.mean():.2f} max {p2_slots.max()}  rows mean {p2_rows.mean():.1f} max {p2_rows.max()}  "
+              f"cycles in the row batches mean {p2_batch.mean():.0f} max {p2_batch.max()}")
+        hv = np.argsort(-t[:, 7])[:8]
+        print("  slowest waves (fringe dx cycles, slots, rows, batch cycles):", [(int(t[i, 7]), int(p2_slots[i]), int(p2_rows[i]), int(p2_batch[i])) for i in hv])
         pro = np.floor(t[:, 4] / 65536.0)
         t[:, 4] = t[:, 4] - pro * 65536.0
         print(f"prologue (entry -> first dense pass) mean {pro.mean():.0f}  fringe dx part mean {t[:, 7].mean():.0f} max {t[:, 7].max():.0f}  dense pass mean {t[:, 6].mean():.0f}")
