@@ -427,15 +427,14 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             // Dense pass (pool_bwd1_kernel<..., DENSE>).  Every row takes its first K = P / 2 surviving candidates, so positions
             // p < K are used by (nearly) every row.  Slot (h, l) holds position block + npb * (l * halves + h): lanes
             // l < K / (npb * halves) of every half are dense; rounded down to whole lanes per chunk (a chunk = every cph-th lane
-            // of a half).  Built and measured in round 3: the same gradients, the dense positions at 0.8
-            // of the issue floor -- and the launch no faster than the general pass where a phase holds several dense positions
-            // (headline 0.245 vs 0.241 ms per step, YAGO3-10 0.206 vs 0.204), faster where it holds one (WN18RR: 0.144 vs
-            // 0.149: the general pass's per-run stream building weighs most there).  So: on for one dense position per phase,
-            // MKB_POOL_DENSE=1 / 0 forces it on / off (read per call: the tests switch it within one process).
+            // of a half).  Round 3: the same gradients; per step, same box, general vs dense pass:
+            // headline 0.242 -> 0.240 ms, WN18RR 0.150 -> 0.143, YAGO3-10 0.206 -> 0.202, TransE-1000 0.183 -> 0.185.  So: on
+            // for the complex-modulus pair function, off for the real-valued ones; MKB_POOL_DENSE=1 / 0 forces it on / off
+            // (read per call: the tests switch it within one process).
             const char *e = getenv("MKB_POOL_DENSE");
             const int cph = 16 / L.pb_halves;
             const int ld = (int)((P / 2) / ((int64_t)npb * L.pb_halves)) / cph * cph;
-            const bool on = e ? e[0] == '1' : (ld == cph && cp);
+            const bool on = e ? e[0] == '1' : cp;
             if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
         if (L.bwd1) {

@@ -33,7 +33,7 @@ namespace mkb {
 constexpr int TI = 8;       // batch rows (fwd / bwd_q) or pool positions (bwd_x) per tile
 constexpr int kRing = 4;    // prefetch depth of the streamed operand (positions / rows in flight per lane)
 constexpr int kRing1 = 3;   // candidate rows in flight per lane in the single-pass backward
-constexpr int kRingF = 2;   // ... of the fringe's dq half when the dense pass is on (few positions per wave)
+constexpr int kRingF = 1;   // ... of the fringe's dq half when the dense pass is on (few positions per wave; every unrolled copy is cold code)
 constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8 rows / positions takes the branch-free body
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 2048; // pool positions supported (= the device sampler's limit, size <= 1024)
@@ -59,6 +59,7 @@ struct PoolArgs {
     int x_blocks, q_first; // merged backward launch: q_first dq blocks, then x_blocks dx blocks, then the other dq blocks
     int dim_slices, pb_halves, tiles_per_wave;  // single-pass backward (pool_bwd1_kernel)
     int dense_lanes;             // ... lanes [0, dense_lanes) of every half hold positions of the dense prefix (0 = no dense pass)
+    int lds_ids_off;             // ... dense pass: offset (ints, behind the header) of the block's pool-id table in LDS
     float *dXp;                  // [row groups][blocks][slots][dim slices][64][NC] dx partials of the single-pass backward
     unsigned long long *xused;   // [row groups][blocks][8] used-slot masks of each (row group, block)
     DxReduce *dx_reduce_out;     // host side: non-null = do not launch the reduction, describe it here instead
@@ -735,6 +736,9 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     int *s_done = (DENSE ? lds1 : lds1 + (size_t)acc_slots * NC * 64) + 16;  // [NW] phases finished by each wave (hand-off chain, see below)
     acc_t *s_x = s_dx + (size_t)acc_slots * 64;  // DENSE: [acc_slots][64] the workgroup's slices of the dense positions' candidate rows
     acc_t *s_q = s_dx;                           // DENSE, one tile per wave: [16 waves x 8 rows][64] query rows, once the dense pass is over
+    // DENSE: pool id of every slot of the block, behind everything else (launch_bwd1: + cap * 8 bytes): the fringe's dx half
+    // asks for a slot's candidate row without a round trip for its id first
+    int64_t *s_ids = reinterpret_cast<int64_t *>(lds1 + HDR + A.lds_ids_off);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell the compiler it is wave-uniform (scalar control flow)
@@ -753,6 +757,10 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     if (tid < halves) s_used[tid] = 0ull;
     if (tid < NW) s_done[tid] = 0;
     if constexpr (DENSE) {
+        for (int sl = tid; sl < cap; sl += WG) {
+            const int p = pb + npb * ((sl & 63) * halves + (sl >> 6));
+            s_ids[sl] = p < A.P ? A.pool[p] : 0;
+        }
         // the candidate rows of the dense positions, one image per accumulator slot: wave w fills the slots of chunk w
         // (the chunk it owns in phase 0); the loads of the chunk are issued together
         const int cph0 = kChunks / halves, lc0 = __builtin_ctz((unsigned)cph0), nd0 = A.dense_lanes >> lc0;
@@ -1299,7 +1307,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         // for up to four slots at once.
         __syncthreads();
         MKB_TRACE_ONLY(const unsigned long long tf0 = __builtin_readcyclecounter();)
-        constexpr int NB = 16;
+        constexpr int NB = 4;  // rows per batch: SMALL on purpose -- this code runs once per launch, and every 64 bytes of it are an instruction-cache miss the first time (a 16-row batch, unrolled, cost more in cold code than it saved in round trips)
         const int row_tiles2 = (A.B + TI - 1) / TI;
         const unsigned long long fmask = A.dense_lanes >= 64 ? 0ull : ~0ull << A.dense_lanes;
         int n_used = 0;
@@ -1324,18 +1332,16 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         float n_gsx = 0.f, n_gsy = 0.f, nx0[KPT], nx1[KPT];
         int n_h = 0, n_j = 0;
         int64_t n_id = 0;
-        auto request = [&](int r) {  // seeds and pool id of slot rank r (nothing is waited for here)
+        auto request = [&](int r) {  // seeds and candidate row of slot rank r (nothing is waited for here)
             if (r >= n_used) return;
             nth_slot(r, n_h, n_j);
-            n_id = A.pool[pb + npb * (n_j * halves + n_h)];
+            n_id = s_ids[n_h * 64 + n_j];
+            load_units_raw<CP, KPT>(A.ent + n_id * A.De, A.d, NU, u0, nx0, nx1);  // (lanes past the row's end: never read back)
             n_gsx = 0.f; n_gsy = 0.f;
             if (tile_l0 < row_tiles2) {
                 const float2 gs = *reinterpret_cast<const float2 *>(A.G + ((((int64_t)tile_l0 * npb + pb) * halves + n_h) * 64 + n_j) * 8 + (lane & 3) * 2);
                 n_gsx = gs.x; n_gsy = gs.y;
             }
-        };
-        auto request_row = [&](int r) {  // ... its candidate row, once the id is in (lanes past the row's end: never read back)
-            if (r < n_used) load_units_raw<CP, KPT>(A.ent + n_id * A.De, A.d, NU, u0, nx0, nx1);
         };
 #pragma unroll
         for (int v = 0; v < KPT; ++v) { nx0[v] = 0.f; nx1[v] = 0.f; }
@@ -1343,7 +1349,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         // the heaviest slot of one round gets the lightest of the next
         auto rank_of = [&](int k) { return k * NW + ((k & 1) ? NW - 1 - wave : wave); };
         request(rank_of(0));
-        request_row(rank_of(0));
         for (int k = 0, r = rank_of(0); k * NW < n_used; ++k, r = rank_of(k)) {
             if (r >= n_used) continue;  // (only in the last round; nothing was requested for it)
             const int r_next = (k + 1) * NW < n_used ? rank_of(k + 1) : n_used;
@@ -1442,7 +1447,6 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 }
                 MKB_TRACE_ONLY(tr_p2batch += __builtin_readcyclecounter() - tb0;)
             }
-            request_row(r_next);
 #pragma unroll
             for (int v = 0; v < KPT; ++v) {
                 dx0[v] = (ax0[0][v] + ax0[1][v]) + (ax0[2][v] + ax0[3][v]);
@@ -1614,11 +1618,13 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     const bool dense_cfg = A.g_blocked && L.dense_lanes > 0;
     const size_t lds_pass = (size_t)2 * L.pb_halves * L.dense_lanes * NC * 64 * 4;  // accumulator + row images of the dense slots
     const size_t lds_rows = L.tiles_per_wave == 1 ? (size_t)kBwd1Waves * TI * NC * 64 * 4 : 0;  // ... then the workgroup's query rows
-    const size_t lds = dense_cfg ? (lds_pass > lds_rows ? lds_pass : lds_rows) + 128
+    const size_t lds_main = lds_pass > lds_rows ? lds_pass : lds_rows;
+    const size_t lds = dense_cfg ? lds_main + 128 + (size_t)L.pb_halves * 64 * 8  // + the block's pool-id table
                                  : (size_t)L.pb_halves * 64 * NC * 64 * 4 + 128;
     PoolArgs A2 = A;
     A2.q_slices = L.q_slices; A2.dim_slices = L.dim_slices; A2.pb_halves = L.pb_halves; A2.tiles_per_wave = L.tiles_per_wave;
     A2.dense_lanes = A.g_blocked ? L.dense_lanes : 0;  // (the dense pass reads the blocked seed layout)
+    A2.lds_ids_off = (int)(lds_main / 4);
     const bool dense = A2.dense_lanes > 0;
     static size_t lds_ok[2] = {0, 0};  // per instantiation: opt in to more than 64 KB of dynamic LDS once
     if (lds > 64 * 1024 && lds > lds_ok[dense]) {
