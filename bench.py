@@ -594,6 +594,9 @@ def main():
                          "exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce")
     ap.add_argument("--force-parallelism", action="store_true",
                     help="N=1: run the table-rows code path on the one GPU (world 1, no collective): the per-rank compute of that path")
+    ap.add_argument("--rccl-world1", action="store_true",
+                    help="N=1: the table-rows code path with a world-1 `nccl` process group and MKB_ROWS_FORCE_COLLECTIVES=1 -- every "
+                         "collective of the step is issued through RCCL instead of being short-circuited (1-GPU boxes only)")
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (default: the headline; the others are for profiles/)")
     ap.add_argument("--mrr-epochs", type=int, default=30,
@@ -614,6 +617,18 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
+    if world == 1 and args.rccl_world1:
+        import socket
+
+        import torch.distributed as dist
+
+        os.environ["MKB_ROWS_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        args.force_parallelism, args.parallelism = True, "table-rows"
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     if world > 1:
         import torch.distributed as dist
 
@@ -666,6 +681,13 @@ def main():
             out["roofline"]["step"] = step_roofline(res, world)
         if failures:
             out["partitioning_failures"] = failures
+        if ctx["trows"]:
+            from mkb_amd.table_rows import _collectives_run, _Route
+
+            out["table_rows"] = {"collectives_issued": bool(_collectives_run(world)), "backend": dist.get_backend() if dist is not None and dist.is_initialized() else None,
+                                 "host_waits_that_blocked": _Route.host_waits, "steps_counted": args.warmup + 8 + args.steps,
+                                 "note": "host_waits_that_blocked = steps whose split sizes (read back one batch ahead on a side stream) "
+                                         "were not there yet when the step needed them"}
 
     # ---- N > 1: the other partitionings and BASELINE configs[4] in the same run (fewer steps; same barrier + max-over-ranks
     # timing).  A watchdog prints the line without them if they hang: the headline number must not be lost to an extra.
@@ -722,7 +744,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(rows=args.cpu_rows)
     print(json.dumps(out))
-    if world > 1:
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MKB_ABI_VERSION 3
+#define MKB_ABI_VERSION 4
 
 typedef enum {
     MKB_OK = 0,
@@ -250,7 +250,10 @@ int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, fl
  * mkb_rows_scatter_add: grad[ids[j]] += rows[j] (fp32 atomics: duplicates add); rider: dense_dst [dense_n] += dense_src.
  * occ (optional, [n_local] uint32, zero-initialised ONCE by the caller): the gather launch counts how often each shard row
  *   is listed in its segments; the scatter launch of the SAME segments adds rows listed once without atomics and resets the
- *   counts.  null = always atomics. */
+ *   counts.  null = always atomics.
+ * bad (optional, int32 [1], zeroed by the caller): ids the reference's gather would answer with IndexError
+ *   (models/base.py:193-207) never touch memory here -- bit 0: a negative id reached mkb_rows_route (routed as id 0);
+ *   bit 1: a shard index outside [0, n_local) reached the gather / scatter (row skipped: zeros / nothing added). */
 typedef struct {
     const int64_t *ids;
     int64_t n;
@@ -259,12 +262,12 @@ typedef struct {
     int64_t *local_ids;   /* gather only; may be null */
 } mkb_row_seg_t;
 int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, int world, int64_t row0, int64_t *send_ids,
-                   int32_t *slot, int64_t *counts, int64_t *compact, void *stream);
+                   int32_t *slot, int64_t *counts, int64_t *compact, int32_t *bad, void *stream);
 int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
                     const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes, uint32_t *occ,
-                    void *stream);
+                    int32_t *bad, void *stream);
 int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs, float *dense_dst,
-                         const float *dense_src, int64_t dense_n, uint32_t *occ, void *stream);
+                         const float *dense_src, int64_t dense_n, uint32_t *occ, int32_t *bad, void *stream);
 /* mkb_adam_rows_advance (grad != null) / mkb_adam_rows_catchup (grad == null) for a shard of such a table: the rows to visit
  * are global_ids [n_global] (entries other ranks own are skipped) followed by local_ids [n_local_ids] (shard indices).
  * Negative entries of any id list of the row-lazy calls are skipped. */

@@ -142,6 +142,17 @@ class Pipeline:
         if self.device_batches and not isinstance(dataset, DeviceBatches):
             dataset = DeviceBatches(dataset, device=self.device, seed=getattr(dataset, "seed", None) or 42)
         fused = self._fused_step_for(model, dataset, sampling, optimizer, loss)
+        try:
+            self._learn(fused, model, dataset, sampling, optimizer, loss, evaluation)
+            if hasattr(model, "sync_parameters"):
+                model.sync_parameters()  # a row-lazy / deferring optimizer leaves nothing pending behind learn()
+        finally:
+            # also on an exception / KeyboardInterrupt inside the loop: a deferred step still pending in the table's gradient
+            # rows is applied and the optimizer goes back to torch.optim semantics before the caller's code sees it
+            self._give_back(optimizer)
+        return self
+
+    def _learn(self, fused, model, dataset, sampling, optimizer, loss, evaluation):
         patience = _Patience(self.early_stopping_rounds)
         for epoch in range(self.epochs):
             self._run_epoch(epoch, fused, model, dataset, sampling, optimizer, loss)
@@ -158,10 +169,6 @@ class Pipeline:
         else:
             print("\n Epoch: %d. \n" % epoch)
             self._score_splits(evaluation, model, dataset)  # (the reference, too, needs an evaluation object here)
-        if hasattr(model, "sync_parameters"):
-            model.sync_parameters()  # a row-lazy / deferring optimizer leaves nothing pending behind learn()
-        self._give_back(optimizer)
-        return self
 
     @classmethod
     def print_metrics(cls, description, metrics):

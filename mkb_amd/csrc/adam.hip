@@ -454,7 +454,10 @@ namespace mkb {
 // +12 us, YAGO3-10 ~40 us per launch if spread evenly).  It is NOT spread evenly when entities are rare: a YAGO3-10 entity
 // that only the random pool reaches waits ~1,500 steps in the tail, its chain is serial, and the launch lasts as long as
 // its longest chain (99 us measured).  So when the mean gap N / rows-per-step is large, each per-step launch also visits
-// a moving window of N / period rows: every row is brought up to date at least once per `period` steps.  Same
+// a moving window of min(N / period, rows-of-this-launch) rows: every row is brought up to date at least once per
+// max(period, N / rows-per-launch) steps (the window never exceeds the launch's own row count, so for N > period * rows the
+// bound is N / rows; the window's start is a function of the step and of THAT launch's window, so launches with different row
+// counts -- a catch-up of a few ids between two training steps -- move it unevenly: a latency aid, not a guarantee).  Same
 // arithmetic, same results bit for bit (every pending step of every row is replayed exactly once, whenever that happens);
 // cost: the window's rows x (p, m, v) in + out.  YAGO3-10: 99 -> 64 us per launch, step 0.268 -> 0.211 ms; WN18RR / FB15k-237
 // (mean gap 18 / 6 steps, every entity is a positive often enough): no gain, so no sweep.
@@ -560,12 +563,8 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
     const int64_t rows = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
-    static bool big_lds = false;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once (160 KB per CU)
-    if (!big_lds) {
-        MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&adam_rows_catchup_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        big_lds = true;
-    }
+    static LdsOptIn big_lds;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once per device (160 KB per CU)
+    if (int rc = big_lds.ensure(reinterpret_cast<const void *>(&adam_rows_catchup_kernel), 96 * 1024)) return rc;
     hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows + extra)), dim3(kCatchThreads), lds, st, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;

@@ -26,6 +26,24 @@ int set_error(int code, const char *fmt, ...);
 
 #define MKB_LAUNCH_CHECK() MKB_CHECK_HIP(hipGetLastError())
 
+// Opt-in to more than 64 KB of dynamic LDS for a kernel.  The attribute is per DEVICE (and per kernel), so what has been
+// granted is remembered per device: a second GPU driven from the same process gets its own opt-in.  One object per kernel
+// (instantiation): `static LdsOptIn grant; if (int rc = grant.ensure(fn, bytes)) return rc;`
+struct LdsOptIn {
+    static constexpr int kMaxDevices = 64;
+    size_t granted[kMaxDevices] = {};
+    int ensure(const void *fn, size_t bytes) {
+        if (bytes <= 64 * 1024) return MKB_OK;
+        int dev = 0;
+        MKB_CHECK_HIP(hipGetDevice(&dev));
+        const bool tracked = dev >= 0 && dev < kMaxDevices;
+        if (tracked && bytes <= granted[dev]) return MKB_OK;
+        MKB_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (tracked) granted[dev] = bytes;
+        return MKB_OK;
+    }
+};
+
 inline int validate_tables(const mkb_tables_t *tb) {
     MKB_REQUIRE(tb != nullptr, "tables is null");
     MKB_REQUIRE(tb->model >= MKB_TRANSE && tb->model <= MKB_PROTATE, "unknown model id %d", tb->model);

@@ -253,12 +253,8 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
     if (seeds.log2_blocks >= 0) {  // tile-blocked seeds: one row tile per 512-lane workgroup, staged through LDS
         const int cap = 64 << (seeds.log2_blocks + seeds.log2_halves);
         if (cap < K) return set_error(MKB_ERR_INVALID, "blocked seed layout holds %d positions, the rows have %d", cap, (int)K);
-        static size_t lds_ok = 0;  // pools of more than ~1800 positions stage more than 64 KB of seeds: opt in once
-        if ((size_t)cap * 9 * 4 > 64 * 1024 && (size_t)cap * 9 * 4 > lds_ok) {
-            MKB_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&adversarial_rows_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, cap * 9 * 4));
-            lds_ok = (size_t)cap * 9 * 4;
-        }
+        static LdsOptIn lds_ok;  // pools of more than ~1800 positions stage more than 64 KB of seeds: opt in once per device
+        if (int rc = lds_ok.ensure(reinterpret_cast<const void *>(&adversarial_rows_kernel<true>), (size_t)cap * 9 * 4)) return rc;
         hipLaunchKernelGGL(adversarial_rows_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(512), (size_t)cap * 9 * 4, st, pos, neg,
                            weight, cnt, (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, occ,
                            occ_sample, occ_pool);

@@ -26,6 +26,7 @@ struct RouteArgs {
     int32_t *slot;          // [2b] position of request j in the grouped order (j < b: head of triple j, else tail of j - b)
     int64_t *counts;        // [world]
     int64_t *compact;       // [b, 3] the triples re-addressed into the compact table: (row0 + slot[j], r, row0 + slot[b + j])
+    int *bad;               // raised for a negative id (the reference raises IndexError, models/base.py:193-207); it is routed as id 0
 };
 
 // One workgroup: a counting sort by owner done as `world` stable compactions (a few block scans of 1024 flags each; the
@@ -43,6 +44,10 @@ __global__ __launch_bounds__(kRouteThreads) void rows_route_kernel(RouteArgs A) 
             bool flag = false;
             if (j < n) {
                 id = A.flat ? A.sample[j] : (j < A.b ? A.sample[3 * (int64_t)j] : A.sample[3 * (int64_t)(j - A.b) + 2]);
+                if (id < 0) {  // (no owner: every request still gets a slot, the caller is told)
+                    if (w == 0 && A.bad) atomicOr(A.bad, 1);
+                    id = 0;
+                }
                 flag = (int)(id % A.world) == w;
             }
             const unsigned long long bal = __ballot(flag);
@@ -85,7 +90,8 @@ struct RowSeg {
 
 struct RowMoveArgs {
     float *shard;        // gather: the table shard (read); scatter: its dense gradient (atomically added to)
-    int64_t D;
+    int64_t D, n_local;  // rows of the shard: an index outside [0, n_local) is skipped and reported through `bad`
+    int *bad;
     RowSeg seg[kMaxSegs];
     int n_segs, row_blocks;
     // riders behind the row workgroups
@@ -109,11 +115,22 @@ __device__ __forceinline__ bool locate(const RowMoveArgs &A, int block, int &s, 
     return s < A.n_segs;
 }
 
-// shard row of entry j of a segment, or -1 when another rank owns it
-__device__ __forceinline__ int64_t shard_row(const RowSeg &S, int j) {
+// shard row of entry j of a segment, or -1 when another rank owns it (or when the index is outside the shard: an id the
+// reference would answer with IndexError -- here the row is skipped and the caller's flag raised, never touched)
+__device__ __forceinline__ int64_t shard_row(const RowMoveArgs &A, const RowSeg &S, int j) {
     const int64_t id = S.ids[j];
-    if (S.world <= 0) return id;
-    return (int)(id % S.world) == S.rank ? id / S.world : -1;
+    int64_t r = id;
+    if (S.world > 0) {
+        if (id >= 0 && (int)(id % S.world) != S.rank) return -1;
+        r = id < 0 ? id : id / S.world;
+    } else if (id == -1) {
+        return -1;  // (an entry the gather marked "not mine" in a local id list)
+    }
+    if (r < 0 || r >= A.n_local) {
+        if (threadIdx.x == 0 && A.bad) atomicOr(A.bad, 2);
+        return -1;
+    }
+    return r;
 }
 
 __global__ __launch_bounds__(kRowThreads) void rows_gather_kernel(RowMoveArgs A) {
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_gather_kernel(RowMoveArgs A)
     }
     if (!locate(A, (int)blockIdx.x, s, j)) return;
     const RowSeg &S = A.seg[s];
-    const int64_t r = shard_row(S, j);
+    const int64_t r = shard_row(A, S, j);
     if (tid == 0 && S.local_ids) S.local_ids[j] = r;
     if (tid == 0 && A.occ && r >= 0) atomicAdd(A.occ + r, 1u);
     float *out = S.rows + (int64_t)j * A.D;
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_scatter_add_kernel(RowMoveAr
     }
     if (!locate(A, (int)blockIdx.x, s, j)) return;
     const RowSeg &S = A.seg[s];
-    const int64_t r = shard_row(S, j);
+    const int64_t r = shard_row(A, S, j);
     if (r < 0) return;
     const float *in = S.rows + (int64_t)j * A.D;
     float *g = A.shard + r * A.D;
@@ -225,11 +242,11 @@ static int fill_segs(RowMoveArgs &A, const mkb_row_seg_t *segs, int n_segs, int6
 using namespace mkb;
 
 extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, int world, int64_t row0, int64_t *send_ids,
-                              int32_t *slot, int64_t *counts, int64_t *compact, void *stream) {
+                              int32_t *slot, int64_t *counts, int64_t *compact, int32_t *bad, void *stream) {
     MKB_REQUIRE(ids && send_ids && slot && counts, "null pointer");
     MKB_REQUIRE(n > 0 && 2 * n <= INT32_MAX && world >= 1 && world <= 4096, "bad n / world");
     MKB_REQUIRE(sample_layout || !compact, "the compact triples need the [b, 3] layout");
-    RouteArgs A{ids, sample_layout ? (int)n : 0, world, sample_layout ? 0 : 1, (int)n, row0, send_ids, slot, counts, compact};
+    RouteArgs A{ids, sample_layout ? (int)n : 0, world, sample_layout ? 0 : 1, (int)n, row0, send_ids, slot, counts, compact, bad};
     hipLaunchKernelGGL(rows_route_kernel, dim3(1), dim3(kRouteThreads), 0, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
@@ -237,7 +254,7 @@ extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, 
 
 extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
                                const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes,
-                               uint32_t *occ, void *stream) {
+                               uint32_t *occ, int32_t *bad, void *stream) {
     MKB_REQUIRE(shard && n_local > 0 && D > 0, "bad shard");
     MKB_REQUIRE((D & 3) != 0 || (((uintptr_t)shard) & 15) == 0, "shard must be 16-byte aligned");
     MKB_REQUIRE(!weight_sum || (weight && n_weight > 0 && n_weight <= INT32_MAX), "bad weights");
@@ -245,7 +262,7 @@ extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, c
                 "the buffer to clear must be 16-byte aligned and hold whole floats");
     RowMoveArgs A{};
     A.shard = const_cast<float *>(shard);
-    A.D = D;
+    A.D = D; A.n_local = n_local; A.bad = bad;
     if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
     A.weight = weight; A.n_weight = (int)n_weight; A.weight_sum = weight_sum;
     A.occ = occ;
@@ -262,12 +279,13 @@ extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, c
 }
 
 extern "C" int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
-                                    float *dense_dst, const float *dense_src, int64_t dense_n, uint32_t *occ, void *stream) {
+                                    float *dense_dst, const float *dense_src, int64_t dense_n, uint32_t *occ, int32_t *bad,
+                                    void *stream) {
     MKB_REQUIRE(grad && n_local > 0 && D > 0, "bad gradient shard");
     MKB_REQUIRE(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "bad dense rider");
     RowMoveArgs A{};
     A.shard = grad;
-    A.D = D;
+    A.D = D; A.n_local = n_local; A.bad = bad;
     if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
     A.dense_dst = dense_dst; A.dense_src = dense_src; A.dense_n = dense_n;
     A.occ = occ;

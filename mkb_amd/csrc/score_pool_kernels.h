@@ -1626,12 +1626,11 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     A2.dense_lanes = A.g_blocked ? L.dense_lanes : 0;  // (the dense pass reads the blocked seed layout)
     A2.lds_ids_off = (int)(lds_main / 4);
     const bool dense = A2.dense_lanes > 0;
-    static size_t lds_ok[2] = {0, 0};  // per instantiation: opt in to more than 64 KB of dynamic LDS once
-    if (lds > 64 * 1024 && lds > lds_ok[dense]) {
+    static LdsOptIn lds_ok[2];  // per instantiation: opt in to more than 64 KB of dynamic LDS once per device
+    if (lds > 64 * 1024) {
         const void *fn = dense ? reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, true>)
                                : reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, false>);
-        MKB_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_ok[dense] = 160 * 1024;
+        if (int rc = lds_ok[dense].ensure(fn, 160 * 1024)) return rc;
     }
     const int row_tiles = (A.B + TI - 1) / TI, per_group = kBwd1Waves * L.tiles_per_wave;
     const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);

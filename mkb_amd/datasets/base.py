@@ -56,13 +56,33 @@ class TrainDataset(Dataset):
     def __getitem__(self, idx):
         return self.triples[idx], self.weights[idx: idx + 1], self.mode
 
+    def __getitems__(self, indices):
+        """The whole batch in one indexed read.  torch's DataLoader fetches a batch through this hook when a dataset has it
+        (``torch/utils/data/_utils/fetch.py``) and hands the result to ``collate_fn`` -- same sampler, same indices, same
+        order, same tensors as ``collate_fn([self[i] for i in indices])`` (the reference's per-triple ``__getitem__`` +
+        ``stack`` / ``cat``, mkb/datasets/base.py:78-90), without 1024 Python calls per batch: the host producer drops from
+        ~10 ms to ~0.1 ms per 1024-row batch, which is what lets an unchanged script keep a GPU step of ~0.25 ms fed."""
+        index = torch.as_tensor(indices, dtype=torch.int64)
+        return _Batch(self.triples[index], self.weights[index], self.mode)
+
     @staticmethod
     def collate_fn(data):
+        if isinstance(data, _Batch):  # already batched by __getitems__
+            return {"sample": data.sample, "weight": data.weight, "mode": data.mode}
         return {
             "sample": torch.stack([d[0] for d in data], dim=0),
             "weight": torch.cat([d[1] for d in data], dim=0),
             "mode": data[0][2],
         }
+
+
+class _Batch:
+    """What ``TrainDataset.__getitems__`` hands to ``collate_fn``."""
+
+    __slots__ = ("sample", "weight", "mode")
+
+    def __init__(self, sample, weight, mode):
+        self.sample, self.weight, self.mode = sample, weight, mode
 
 
 class _TrueIndex:

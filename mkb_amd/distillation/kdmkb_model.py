@@ -34,6 +34,7 @@ class KdmkbModel:
         self.n_random_entities, self.n_random_relations = n_random_entities, n_random_relations
         self.update_distillation_every, self.device, self.seed, self.warm_step = update_distillation_every, device, seed, warm_step
         self.sampling_method = sampling_method
+        self.rebuild_teacher_independent = True  # the reference's unconditional rebuild (kdmkb_model.py:418); see learn()
         self._rng = np.random.RandomState(seed)
         ids = list(datasets)
         for key, dataset in datasets.items():
@@ -107,9 +108,12 @@ class KdmkbModel:
             weight_kl = {k: 0 for k in datasets} if step < self.warm_step else dict(self.alpha_kl)
             metrics = self.forward(datasets, models, weight_kl)
             bar.set_description(text=", ".join(f"{k}: {v.get():4f}" for k, v in metrics.items()))
-            if (step + 1) % self.update_distillation_every == 0 and getattr(self.sampling_method, "depends_on_teacher", True):
-                # (the reference rebuilds to refresh its faiss top-k indexes of the teacher; a teacher-independent sampler
-                # -- UniformSampling -- would only be re-seeded and repeat its draws every update_distillation_every steps)
+            if (step + 1) % self.update_distillation_every == 0 and (
+                    self.rebuild_teacher_independent or getattr(self.sampling_method, "depends_on_teacher", True)):
+                # The reference rebuilds unconditionally (kdmkb_model.py:418), to refresh its faiss top-k indexes of the
+                # teacher; a teacher-independent sampler -- UniformSampling -- is only re-seeded by that and repeats its
+                # draws every update_distillation_every steps.  Default: the reference's behaviour (same draw sequence for
+                # seeded comparison runs); `rebuild_teacher_independent = False` opts out of the re-seeding.
                 for name in self.distillation:
                     teacher, student = name.split("_", 1) if name.count("_") == 1 else self._split(name, datasets)
                     self.distillation[name] = self._make_distillation(models, datasets, teacher, student)

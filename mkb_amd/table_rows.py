@@ -28,6 +28,8 @@ Backends.  The row movement goes through a small ``ops`` object: ``HipRowOps`` (
 (``gloo``, oracle as the compute step) inject their own torch restatement (``tests/row_ops_torch.py``).
 """
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -44,10 +46,39 @@ def _rank(group):
     return dist.get_rank(group) if dist.is_initialized() else 0
 
 
+def _collectives_run(world):
+    """World 1 short-circuits every collective (the sum over one rank IS the operand) -- unless MKB_ROWS_FORCE_COLLECTIVES=1
+    and a process group exists: then a 1-GPU box drives every call of the step (all_to_all_single with split sizes, the packed
+    all-reduces, the side-stream read-back of the counts) through the real backend (``nccl`` = RCCL), which is how this path
+    is exercised on hardware where only one GPU can be reached (tests/test_gpu_rccl_world1.py)."""
+    return world > 1 or (os.environ.get("MKB_ROWS_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized())
+
+
 class HipRowOps:
     """Row movement on the device (``mkb_rows_route`` / ``mkb_rows_gather`` / ``mkb_rows_scatter_add``).  A segment is
     ``(ids, rows, world, rank, local_ids_out)``: ``world == 0`` -> ``ids`` are shard indices; ``world > 0`` -> global
-    entity ids, only this rank's entries are touched."""
+    entity ids, only this rank's entries are touched.
+
+    Ids the reference's gather would answer with ``IndexError`` (mkb/models/base.py:193-207) never touch memory: the kernels
+    skip them and raise a device flag that ``check()`` turns into that ``IndexError`` (one read-back, when the caller asks:
+    ``TableRowShardedStep.check()``, like ``model.check_ids()`` on the single-GPU path)."""
+
+    def __init__(self):
+        self._bad = {}
+
+    def _flag(self, dev):
+        flag = self._bad.get(dev)
+        if flag is None:
+            flag = self._bad[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return flag
+
+    def check(self):
+        for dev, flag in self._bad.items():
+            bits = int(flag.item())
+            if bits:
+                flag.zero_()
+                what = [w for b, w in ((1, "a negative entity id was routed"), (2, "a row index outside the table shard was listed")) if bits & b]
+                raise IndexError("row-sharded table: " + " and ".join(what) + " (skipped on the device)")
 
     @staticmethod
     def _segs(segs):
@@ -70,7 +101,8 @@ class HipRowOps:
         compact = torch.empty((n, 3), dtype=torch.int64, device=dev) if sample_layout else None
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_rows_route(_hip.ptr(ids), n, 1 if sample_layout else 0, world, row0, _hip.ptr(send),
-                                                 _hip.ptr(slot), _hip.ptr(counts), _hip.ptr(compact), _hip.stream_ptr()),
+                                                 _hip.ptr(slot), _hip.ptr(counts), _hip.ptr(compact), _hip.ptr(self._flag(dev)),
+                                                 _hip.stream_ptr()),
                        "mkb_rows_route")
         return send, slot, counts, compact
 
@@ -82,7 +114,8 @@ class HipRowOps:
             _hip.check(_hip.lib().mkb_rows_gather(
                 _hip.ptr(shard), shard.shape[0], shard.shape[1], self._segs(segs), len(segs), _hip.ptr(weight),
                 0 if weight is None else weight.numel(), _hip.ptr(weight_sum), _hip.ptr(zero),
-                0 if zero is None else zero.numel() * zero.element_size(), _hip.ptr(occ), _hip.stream_ptr()),
+                0 if zero is None else zero.numel() * zero.element_size(), _hip.ptr(occ), _hip.ptr(self._flag(shard.device)),
+                _hip.stream_ptr()),
                 "mkb_rows_gather")
 
     def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
@@ -90,7 +123,8 @@ class HipRowOps:
         with torch.cuda.device(grad.device):
             _hip.check(_hip.lib().mkb_rows_scatter_add(
                 _hip.ptr(grad), grad.shape[0], grad.shape[1], self._segs(segs), len(segs), _hip.ptr(dense_dst),
-                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(occ), _hip.stream_ptr()),
+                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(occ), _hip.ptr(self._flag(grad.device)),
+                _hip.stream_ptr()),
                 "mkb_rows_scatter_add")
 
 
@@ -126,7 +160,7 @@ class RowShardedTable:
     def gather_shared(self, ids):
         out = torch.empty((ids.numel(), self.dim), dtype=self.data.dtype, device=self.data.device)
         self.ops.gather(self.data.detach(), [(ids, out, self.world, self.rank, None)])
-        if self.world > 1:
+        if _collectives_run(self.world):
             dist.all_reduce(out, group=self.group)  # disjoint supports: the sum IS the gather, exactly
         return out
 
@@ -163,24 +197,30 @@ class _Route:
     sizes of the all-to-alls and sends the id lists: ``want`` = the shard indices the other ranks ask this owner for."""
 
     _side = {}
+    host_waits = 0  # resolve() calls that found the read-back of their counts still in flight (the host then waits for it)
 
     def __init__(self, table, n, send_ids, slot, counts, compact):
         self.table, self.n = table, n
         self.send_ids, self.slot, self.counts, self.compact = send_ids, slot, counts, compact
         self.sc = self.rc = self.want = None
-        self._host = self._event = None
+        self._host = self._event = self._ready = None
+
+    @classmethod
+    def side_stream(cls, dev):
+        side = cls._side.get(dev)
+        if side is None:
+            side = cls._side[dev] = torch.cuda.Stream(device=dev)
+        return side
 
     def exchange_counts(self):
         tb = self.table
-        if tb.world == 1:
+        if not _collectives_run(tb.world):
             return
         both = torch.empty(2 * tb.world, dtype=torch.int64, device=self.counts.device)
         both[: tb.world] = self.counts
         work = dist.all_to_all_single(both[tb.world:], both[: tb.world], group=tb.group, async_op=True)
         if both.is_cuda:  # read back beside the compute stream: the host waits for THIS copy only, never for the step's kernels
-            side = self._side.get(both.device)
-            if side is None:
-                side = self._side[both.device] = torch.cuda.Stream(device=both.device)
+            side = self.side_stream(both.device)
             self._host = torch.empty(2 * tb.world, dtype=torch.int64, pin_memory=True)
             with torch.cuda.stream(side):
                 if work is not None:
@@ -200,13 +240,17 @@ class _Route:
         if self.want is not None:
             return
         tb = self.table
-        if tb.world == 1:
+        if self._ready is not None:  # the route was made on the side stream: the step's stream takes over from here
+            torch.cuda.current_stream(self.send_ids.device).wait_event(self._ready)
+        if not _collectives_run(tb.world):
             self.sc, self.rc = [self.n], [self.n]
             self.listed = torch.empty(lead + self.n, dtype=torch.int64, device=self.send_ids.device)
             self.want = self.listed[lead:]
             self.want.copy_(self.send_ids)
             return
         if self._event is not None:
+            if not self._event.query():
+                _Route.host_waits += 1
             self._event.synchronize()
         host = self._host.tolist()
         self.sc, self.rc = host[: tb.world], host[tb.world:]
@@ -216,14 +260,14 @@ class _Route:
 
     # rows [sum(rc), D] read by this owner -> the requesters' buffers [n, D] (grouped order), and the way back
     def rows_to_requesters(self, reply, got, async_op=False):
-        if self.table.world == 1:
+        if not _collectives_run(self.table.world):
             got.copy_(reply)
             return None
         return dist.all_to_all_single(got, reply, output_split_sizes=self.sc, input_split_sizes=self.rc, group=self.table.group,
                                       async_op=async_op)
 
     def rows_to_owners(self, grouped, back, async_op=False):
-        if self.table.world == 1:
+        if not _collectives_run(self.table.world):
             back.copy_(grouped)
             return None
         return dist.all_to_all_single(back, grouped, output_split_sizes=self.rc, input_split_sizes=self.sc, group=self.table.group,
@@ -271,7 +315,7 @@ class TableRowShardedStep:
         self.world, self.ops = table.world, table.ops
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
-        self._bufs, self._models, self._plans = {}, {}, {}
+        self._bufs, self._models, self._plan = {}, {}, None
         self._occ = None
         self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
         if compute is None and self._trains_modulus and modulus is None:
@@ -302,22 +346,60 @@ class TableRowShardedStep:
         return bufs
 
     # ------------------------------------------------------------------ routing, one batch ahead
+    @staticmethod
+    def _batch_key(sample, P):
+        # the batch as the CALLER holds it (before any .contiguous() copy): a view of the same storage is the same batch
+        return (sample.data_ptr(), tuple(sample.shape), tuple(sample.stride()), sample._version, P)
+
     def plan(self, sample, pool_size=None):
-        """Prepare the routing of ``sample``'s positive rows (a later ``step(sample, ...)`` picks it up).  Needs the pool
-        size of that step (``2 * sampler.size``) to address the compact table; defaults to the last step's."""
+        """Prepare the routing of ``sample``'s positive rows; the NEXT ``step(sample, ...)`` must be for that batch (the same
+        tensor or a view of the same storage, unmodified) and picks it up.  Needs the pool size of that step
+        (``2 * sampler.size``) to address the compact table; defaults to the last step's.
+
+        Every rank must plan (or not plan) alike: a plan issues a collective, so ranks that disagreed would hang.  That is why a
+        pending plan is never dropped silently -- a step for another batch raises (``drop_plan()`` discards it, collectively).
+        On a ROCm device the route kernel and the count exchange run on a side stream, beside the step's own launches."""
         P = self._last_P if pool_size is None else pool_size
+        key = self._batch_key(sample, P)
+        kept = sample
         sample = sample if sample.is_contiguous() else sample.contiguous()
         _, _, row0, _ = self._layout(P, sample.shape[0])
-        send_ids, slot, counts, compact = self.ops.route(sample, self.world, row0, sample_layout=True)
-        route = _Route(self.table, 2 * sample.shape[0], send_ids, slot, counts, compact)
-        route.exchange_counts()
-        self._plans = {(sample.data_ptr(), sample.shape[0], P): (route, sample)}  # (keeps `sample` alive: the key stays unique)
+        side = ready = None
+        if sample.is_cuda and _collectives_run(self.world):
+            side = _Route.side_stream(sample.device)
+            side.wait_stream(torch.cuda.current_stream(sample.device))  # (the batch may have been produced on the step's stream)
+        if side is not None:
+            with torch.cuda.stream(side):
+                send_ids, slot, counts, compact = self.ops.route(sample, self.world, row0, sample_layout=True)
+                route = _Route(self.table, 2 * sample.shape[0], send_ids, slot, counts, compact)
+                route.exchange_counts()
+                ready = torch.cuda.Event()
+                ready.record(side)
+            for t in (sample, send_ids, slot, counts, compact):
+                t.record_stream(side)
+            route._ready = ready
+        else:
+            send_ids, slot, counts, compact = self.ops.route(sample, self.world, row0, sample_layout=True)
+            route = _Route(self.table, 2 * sample.shape[0], send_ids, slot, counts, compact)
+            route.exchange_counts()
+        self._plan = (key, route, kept, sample)  # (keeps the tensors alive: the key stays unique)
         return route
 
+    def drop_plan(self):
+        """Discard a pending plan (every rank must do so alike)."""
+        self._plan = None
+
     def _route_for(self, sample, P):
-        hit = self._plans.pop((sample.data_ptr(), sample.shape[0], P), None)
-        route = hit[0] if hit is not None else self.plan(sample, P)
-        self._plans = {}
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan is not None:
+            if plan[0] != self._batch_key(sample, P):
+                raise RuntimeError("the row-sharded step was handed another batch than the one planned for it (plan(next_sample) / "
+                                   "next_sample= must name the very next batch, unmodified, with the same pool size, on every rank); "
+                                   "call drop_plan() on every rank to discard a plan")
+            route = plan[1]
+        else:
+            self.plan(sample, P)
+            route, self._plan = self._plan[1], None
         route.resolve(lead=P)
         return route
 
@@ -367,15 +449,15 @@ class TableRowShardedStep:
 
     def __call__(self, sample, weight, negative_sample, mode, next_sample=None, _sampler=None):
         tb, ops, dev = self.table, self.ops, sample.device
-        sample = sample if sample.is_contiguous() else sample.contiguous()
-        weight = weight if weight.is_contiguous() else weight.contiguous()
         b = sample.shape[0]
         P = 2 * _sampler.size if _sampler is not None else negative_sample._mkb_pool.pool.numel()
         self._last_P = P
+        route = self._route_for(sample, P)  # (keyed on the batch as the caller holds it, before any copy)
+        sample = sample if sample.is_contiguous() else sample.contiguous()
+        weight = weight if weight.is_contiguous() else weight.contiguous()
         D, X, row0, rows = self._layout(P, b)
         bufs = self._buffers(P, b, dev)
         ent, grad = bufs["ent"], bufs["grad"]
-        route = self._route_for(sample, P)
         if next_sample is not None:
             self.plan(next_sample, P)  # its count exchange and read-back overlap this step's kernels
         want = route.want
@@ -398,7 +480,7 @@ class TableRowShardedStep:
                    weight=weight, weight_sum=bufs["wsum"], zero=grad, occ=self._occ)
         # 2. positive rows to their users, pool block (+ weight sum) completed everywhere
         w_rows = route.rows_to_requesters(reply, ent[row0:], async_op=True)
-        w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if self.world > 1 else None
+        w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if _collectives_run(self.world) else None
         for w in (w_rows, w_pool):
             if w is not None:
                 w.wait()
@@ -418,7 +500,7 @@ class TableRowShardedStep:
         #    gradients back to their owners
         back = torch.empty((R, D), dtype=torch.float32, device=dev)
         w_back = route.rows_to_owners(grad[row0:], back, async_op=True)
-        w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if self.world > 1 else None
+        w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if _collectives_run(self.world) else None
         for w in (w_back, w_sum):
             if w is not None:
                 w.wait()
@@ -433,6 +515,12 @@ class TableRowShardedStep:
         if opt is not None:
             _links.mark_touched(tb.data, touched)
         return bufs["loss"].clone().reshape(())
+
+    def check(self):
+        """Raise the reference's ``IndexError`` for ids outside the table that reached the row kernels since the last call (they
+        were skipped on the device, never dereferenced); one small read-back, when the caller asks."""
+        if hasattr(self.ops, "check"):
+            self.ops.check()
 
     @property
     def rank_of_table(self):

@@ -18,13 +18,21 @@ def main():
     from mkb_amd.table_rows import TableRowShardedStep, gather_table_rows, shard_table_rows
 
     name, hidden, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    big = len(sys.argv) > 4 and sys.argv[4] == "big"  # FB15k-237: shards of > 4096 rows step ROW-LAZILY, real step deferred
-    dist.init_process_group("gloo")
+    size = sys.argv[4] if len(sys.argv) > 4 else "small"
+    yago = size == "yago"          # BASELINE config 5's table (123,182 entities) at its batch size: 1024 rows per rank
+    big = size == "big" or yago    # FB15k-237: shards of > 4096 rows step ROW-LAZILY, real step deferred
+    # MKB_TR_BACKEND=nccl: the collectives go through RCCL (one rank per GPU; at world 1 together with
+    # MKB_ROWS_FORCE_COLLECTIVES=1, which keeps the step from short-circuiting them: tests/test_gpu_rccl_world1.py)
+    backend = os.environ.get("MKB_TR_BACKEND", "gloo")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    ds = (datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    ds = (datasets.Yago310 if yago else datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
-    B = (64 if big else 24) * world
+    B = (1024 if yago else 64 if big else 24) * world
     adam_kw = dict(lazy_rows=True, defer_step=True) if big else {}
 
     def batches():
@@ -79,7 +87,8 @@ def main():
         np.testing.assert_allclose(l1, l0, rtol=0, atol=3e-5)
         np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=0, atol=3e-5)
         np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
-        print("TR_OK", name, world)
+        from mkb_amd.table_rows import _collectives_run, _Route
+        print("TR_OK", name, world, backend, "collectives_run", _collectives_run(world), "host_waits", _Route.host_waits)
     dist.barrier()
     dist.destroy_process_group()
 
