@@ -323,10 +323,11 @@ KERNEL_NAMES = {"pool_fwd": ("pool_fwd", "pair_fwd", "gemm"), "pool_bwd_q": ("po
 
 
 def measure_traffic(prof_kind, config):
-    """HBM bytes per launch of the profiled kernel class, measured NOW: two short rocprofv3 PMC passes (FETCH_SIZE, then
-    WRITE_SIZE: the TCC has 4 slots, the two counters need 5) over this same script, as MI355X_MICROARCH.md's HBM section
-    prescribes; FETCH_SIZE doubled (gfx950 tallies a 128-byte request as 64 bytes for wide coalesced reads: calibrated on
-    the dense Adam kernel in round 1), KiB -> bytes.  Returns (bytes or None, note)."""
+    """HBM bytes per launch of the profiled kernel class AND of every mkb:: kernel of a step, measured NOW: two short rocprofv3
+    PMC passes (FETCH_SIZE, then WRITE_SIZE: the TCC has 4 slots, the two counters need 5) over this same script, as
+    MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE doubled (gfx950 tallies a 128-byte request as 64 bytes for wide
+    coalesced reads: calibrated on the dense Adam kernel in round 1), KiB -> bytes.
+    Returns (bytes of the class or None, note, rocprof name of the class's kernel or None, per-step table or None)."""
     import glob
     import shutil
     import sqlite3
@@ -335,11 +336,11 @@ def measure_traffic(prof_kind, config):
 
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None, None
     frags = KERNEL_NAMES.get(prof_kind)
     if not frags:
-        return None, f"no kernel name known for class {prof_kind}"
-    out, notes = {}, []
+        return None, f"no kernel name known for class {prof_kind}", None, None
+    out, notes, names, tables = {}, [], [], {}
     tmp = tempfile.mkdtemp(prefix="mkb_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", MKB_BENCH_INNER="1")
     try:
@@ -351,13 +352,14 @@ def measure_traffic(prof_kind, config):
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}"
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}", None, None
             cur = sqlite3.connect(dbs[0]).cursor()
             per = {}
             for name, val in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
                 a = per.setdefault(name, [0, 0.0])
                 a[0] += 1
                 a[1] += val
+            tables[counter] = per
             best = None
             for frag in frags:  # first fragment that matches; the heaviest kernel of that name
                 hit = [(tot / n, n, name) for name, (n, tot) in per.items() if frag in name]
@@ -365,16 +367,39 @@ def measure_traffic(prof_kind, config):
                     best = max(hit)
                     break
             if best is None:
-                return None, f"no kernel matching {frags} in the {counter} pass"
+                return None, f"no kernel matching {frags} in the {counter} pass", None, None
             out[counter] = best[0] * 1024.0  # KiB per dispatch -> bytes
+            names.append(best[2])
             notes.append(f"{counter} {best[0] * 1024 / 1e6:.1f} MB x {best[1]} launches of {best[2][:60]}")
     except Exception as e:  # noqa: BLE001 -- the profiler is optional equipment: never lose the bench line over it
-        return None, f"traffic pass failed: {type(e).__name__}: {e}"
+        return None, f"traffic pass failed: {type(e).__name__}: {e}", None, None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     total = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+    # the whole step: every mkb:: kernel of the passes, bytes per launch x launches per step (a step = one row_fwd launch;
+    # flush / set-up launches that run once per process are left out: fewer than one launch per two steps)
+    step_table = None
+    try:
+        short = lambda n: n.split("(")[0].replace("void ", "")
+        fe, wr = tables["FETCH_SIZE"], tables["WRITE_SIZE"]
+        n_steps = sum(n for name, (n, _) in fe.items() if "row_fwd_kernel" in name) or sum(n for name, (n, _) in fe.items() if "query_build" in name)
+        per_kernel, per_step = {}, 0.0
+        for name in fe:
+            if "mkb::" not in name or n_steps == 0 or fe[name][0] * 2 < n_steps:
+                continue
+            f_b = 2.0 * fe[name][1] * 1024.0 / n_steps
+            w_b = wr.get(name, [0, 0.0])[1] * 1024.0 / n_steps
+            k = short(name)
+            per_kernel[k] = round(per_kernel.get(k, 0.0) + (f_b + w_b) / 1e6, 2)
+            per_step += f_b + w_b
+        step_table = {"measured_hbm_bytes_per_step": per_step, "per_kernel_MB_per_step": per_kernel, "steps_in_the_pass": n_steps,
+                      "note": "sum over the mkb:: kernels of a step of (2 x FETCH_SIZE + WRITE_SIZE), head- and tail-batch "
+                              "instantiations averaged by their launch counts; TCC counters: L2 <-> fabric traffic, of which the "
+                              "256 MB Infinity Cache absorbs an unknown share before HBM"}
+    except Exception:  # noqa: BLE001
+        step_table = None
     return total, ("measured in this run: rocprofv3 --pmc, separate passes over 12 steps; 2 x FETCH_SIZE + WRITE_SIZE, mean per launch: "
-                   + "; ".join(notes))
+                   + "; ".join(notes)), (names[0].split("(")[0].replace("void ", "") if names else None), step_table
 
 
 def measure(args, device, rank, world, config, parallelism, steps, warmup, profile=True, force=False):
@@ -481,9 +506,17 @@ def roofline_of(res, world, want_traffic):
     De, Dr, N, R = m_.entity_dim, m_.relation_dim, m_.n_entity, m_.n_relation  # per rank (dims: 1/world of the row)
     Bk = world * ctx["rows_per_rank"] if ctx["dims"] else ctx["rows_per_rank"]  # rows each rank's kernels see
     avg_s = res["kms"] / launches / 1e3
-    traffic, traffic_note = (None, "not measured (--no-traffic, N > 1, or a non-default run)")
+    traffic, traffic_note, kname, step_table = (None, "not measured (--no-traffic, N > 1, or a non-default run)", None, None)
     if want_traffic:
-        traffic, traffic_note = measure_traffic(prof_kind, res["config"])
+        traffic, traffic_note, kname, step_table = measure_traffic(prof_kind, res["config"])
+    res["step_traffic"] = step_table
+    # the rocprofv3 name of the class's kernel: taken from the PMC pass when there was one, else spelled from the configuration
+    # (template arguments: model id, head-batch, units per lane, dense pass); the internal class name rides along as `class`
+    mid = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}.get(MODEL, "?")
+    guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else "mkb::gemm128_f32_mfma_kernel<..> (dQ = G . X)"),
+             "pool_fwd": (f"mkb::pool_fwd_tile_kernel<{mid}, true|false, ..>" if MODEL == "RotatE" else f"mkb::pool_fwd_kernel<{mid}, ..>"),
+             "pool_bwd_x": "mkb::gemm128_f32_mfma_kernel<..> (dX = G^T . Q)", "adam": "mkb::adam_rows_catchup_kernel"}.get(prof_kind, prof_kind)
+    kernel_name = kname or guess
     info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
     if prof_kind == "adam":
         lazy_rows = getattr(ctx["opt"], "lazy_rows", False)
@@ -499,7 +532,7 @@ def roofline_of(res, world, want_traffic):
             alg = 8 * 4 * (N * De + R * Dr) / 2.0  # one launch per parameter tensor, averaged over the two
             note = "dense Adam (+zero_grad) kernel: 8 x 4 B per parameter element, averaged over the ent/rel launches"
         ach = alg / avg_s / 1e9
-        return {"bound": "hbm", "kernel": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"bound": "hbm", "kernel": kernel_name, "class": prof_kind, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "avg_kernel_us": avg_s * 1e6,
                 "launches": launches, "algorithmic_bytes_per_launch": alg, "note": note}
     # The pooled kernels reuse every candidate row from registers / LDS / L2 (PMC traffic is ~1/30 of the logical gather
@@ -522,7 +555,7 @@ def roofline_of(res, world, want_traffic):
         flop, trans = float(pairs) * units * per_term[0], float(pairs) * units * per_term[1]
     ach = flop / avg_s / 1e12
     label = "pool_bwd (single pass: dq and dx from one evaluation of every pair term)" if bwd else "pool_fwd"
-    roof = {"bound": "mfma" if mfma else "valu", "kernel": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+    roof = {"bound": "mfma" if mfma else "valu", "kernel": kernel_name, "class": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
             "avg_kernel_us": avg_s * 1e6, "launches": launches, "algorithmic_flop_per_launch": flop,
             "note": (f"{label}: " + (f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}"
@@ -566,7 +599,13 @@ def step_roofline(res, world):
     # (p, m, v, g in; p, m, v, cleared g out): 9 row passes
     byts = 9.0 * rows * De * 4
     s = res["ms_per_step"] / 1e3
-    return {"algorithmic_flop_per_step": flop, "achieved_TFLOPs": flop / s / 1e12, "frac_of_fp32_peak": flop / s / 1e12 / FP32_PEAK_TFLOPS,
+    measured = {}
+    if res.get("step_traffic"):
+        st = res["step_traffic"]
+        measured = {"measured_hbm_bytes_per_step": st["measured_hbm_bytes_per_step"],
+                    "measured_over_compulsory": st["measured_hbm_bytes_per_step"] / byts,
+                    "measured_per_kernel_MB_per_step": st["per_kernel_MB_per_step"], "measured_note": st["note"]}
+    return {**measured, "algorithmic_flop_per_step": flop, "achieved_TFLOPs": flop / s / 1e12, "frac_of_fp32_peak": flop / s / 1e12 / FP32_PEAK_TFLOPS,
             "compulsory_hbm_bytes_per_step": byts, "compulsory_GBps": byts / s / 1e9, "frac_of_hbm_peak": byts / s / 1e9 / HBM_PEAK_GBS,
             "distinct_touched_rows": rows,
             "note": f"SURVEY 8(d): B*K*{flop_per} flop per step (fwd + bwd, per rank); compulsory bytes = {rows} distinct touched rows x "

@@ -60,6 +60,10 @@ typedef struct {
     float *g_ent;             /* [n_entity, entity_dim]   */
     float *g_rel;             /* [n_relation, relation_dim] */
     float *g_modulus;         /* [1] (pRotatE) or null    */
+    int32_t rows_clear;       /* mkb_pool_step / _bwd only, a promise of the caller: the g_ent rows of this batch's entities
+                                 (pool ids, heads, tails) are all-zero on entry (fresh buffers; or the row-lazy optimizer's
+                                 advance launch has just consumed and cleared them).  Rows that a single workgroup writes are
+                                 then stored instead of read-modify-written.  0 = accumulate as always. */
 } mkb_grads_t;
 
 int mkb_abi_version(void);

@@ -32,8 +32,8 @@ class Tables(Structure):
                 ("modulus", c_void_p), ("gamma", c_float), ("phase_div", c_float)]
 
 
-class Grads(Structure):
-    _fields_ = [("g_ent", c_void_p), ("g_rel", c_void_p), ("g_modulus", c_void_p)]
+class Grads(Structure):  # mkb_grads_t; rows_clear (default 0): see include/mkb_hip.h
+    _fields_ = [("g_ent", c_void_p), ("g_rel", c_void_p), ("g_modulus", c_void_p), ("rows_clear", c_int32)]
 
 
 class AdamDense(Structure):  # mkb_adam_dense_t: a small dense tensor stepped inside mkb_adam_rows_step's launch

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
     constexpr int TM = 128, KC = 32, LD = KC + 1, T = 256, NT = TN / 64;
     constexpr int V = TM * KC / 4 / T, VB = TN * KC / 4 / T;  // float4 per lane and K chunk: A (= 4), B (= 4 or 2)
     extern __shared__ __attribute__((aligned(16))) float lds_g[];
+    // two stages of (A tile, B tile): chunk k + 1 is written while chunk k is multiplied -- ONE barrier per chunk (round 3: a
+    // single stage, i.e. a barrier after the writes and another after the multiplies)
+    constexpr int STAGE = (TM + TN) * LD;
     float *sA = lds_g, *sB = lds_g + TM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
     // columns that are never stored; k beyond the range is zeroed when the chunk is written to LDS.  Row indirection:
     // B_NK rows are fixed for the whole K loop (resolved once); B_KN rows change with k: their ids are staged in LDS first
     // (one dependent global round trip per workgroup instead of one per load).
-    int *s_idx = reinterpret_cast<int *>(lds_g + (TM + TN) * LD);  // [kper_] row ids of the K range (B_KN with b_idx)
+    int *s_idx = reinterpret_cast<int *>(lds_g + 2 * STAGE);  // [kper_] row ids of the K range (B_KN with b_idx)
     int64_t brow[VB];
     if constexpr (B_NK) {
 #pragma unroll
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         }
     };
     // full_c: the whole chunk lies inside the K range (every chunk but possibly the last): no per-element range selects
-    auto store_tiles = [&](int k0, auto full_c) {
+    auto store_tiles = [&](int k0, int stage, auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
+        float *sA = lds_g + stage * STAGE, *sB = sA + TM * LD;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             int r, kk;
@@ -269,14 +273,21 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         }
     };
 
-    if (k_lo < k_hi) load_tiles(k_lo);
+    auto store_chunk = [&](int k0, int stage) {
+        if (k0 + KC <= k_hi) store_tiles(k0, stage, std::true_type{});
+        else store_tiles(k0, stage, std::false_type{});
+    };
+    if (k_lo < k_hi) {
+        load_tiles(k_lo);
+        store_chunk(k_lo, 0);
+    }
+    __syncthreads();
+    int stage = 0;
     for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
-        if (k0 + KC <= k_hi) store_tiles(k0, std::true_type{});
-        else store_tiles(k0, std::false_type{});
-        __syncthreads();
-        if (k0 + KC < k_hi) load_tiles(k0 + KC);  // next chunk in flight under this chunk's 64 MFMAs
-        const float *pa = sA + (wm + (lane & 31)) * LD + (lane >> 5);
-        const float *pb = sB + (wn + (lane & 31)) * LD + (lane >> 5);
+        const bool more = k0 + KC < k_hi;
+        if (more) load_tiles(k0 + KC);  // next chunk in flight under this chunk's 64 MFMAs
+        const float *pa = sA + stage * STAGE + (wm + (lane & 31)) * LD + (lane >> 5);
+        const float *pb = sB + stage * STAGE + (wn + (lane & 31)) * LD + (lane >> 5);
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
             const float a0 = pa[kk], a1 = pa[32 * LD + kk], b0 = pb[kk];
@@ -288,7 +299,10 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
+        // the other stage was last read during the previous chunk, and every wave has passed that chunk's barrier since
+        if (more) store_chunk(k0 + KC, stage ^ 1);
         __syncthreads();
+        stage ^= 1;
     }
     float *Cz = G.C + (int64_t)blockIdx.z * G.M * G.ldc;  // partial buffer of this K split (z = 0: C itself)
 #pragma unroll
@@ -372,13 +386,24 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             G.ksplit = ks;
             float *final_c = G.C;
             const int tn = narrow ? 64 : 128;
-            const size_t lds = (size_t)(128 + tn) * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
+            const size_t lds = (size_t)2 * (128 + tn) * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;  // two stages + row ids
             dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + tn - 1) / tn), (unsigned)ks);
+            // (two stages of a 128 x 128 tile pair are 66 KB: more than the 64 KB a kernel gets without asking)
+            auto launch128 = [&](auto epi_c, auto tn_c, const GemmArgs &GA) -> int {
+                constexpr int E = decltype(epi_c)::value, TNv = decltype(tn_c)::value;
+                static LdsOptIn grant;  // (one per instantiation of this generic lambda)
+                auto *fn = &gemm128_f32_mfma_kernel<A_MK, B_NK, E, TNv>;
+                if (int rc = grant.ensure(reinterpret_cast<const void *>(fn), lds)) return rc;
+                hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, GA);
+                return MKB_OK;
+            };
+            typedef std::integral_constant<int, 64> tn64_t;
+            typedef std::integral_constant<int, 128> tn128_t;
             if (EPI == GEMM_ATOMIC_ROWS && partials) {  // partial products [ks, M, N], then one scattered add per element
                 GemmArgs P2 = G;
                 P2.C = partials; P2.ldc = G.N;
-                if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 64>), grid, dim3(256), lds, st, P2);
-                else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, GEMM_STORE, 128>), grid, dim3(256), lds, st, P2);
+                typedef std::integral_constant<int, GEMM_STORE> store_t;
+                if (int rc = narrow ? launch128(store_t{}, tn64_t{}, P2) : launch128(store_t{}, tn128_t{}, P2)) return rc;
                 const int *dp = G.depth_mode == 3 ? G.depth : nullptr;
                 if (tail) *tail = GemmTail{2, partials, final_c, G.c_idx, G.M, G.N, ks, G.ldc, 0, 0.f, 1.f, dp, G.n_depth};
                 else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M,
@@ -387,8 +412,8 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
                 return MKB_OK;
             }
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) G.C = partials;
-            if (narrow) hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI, 64>), grid, dim3(256), lds, st, G);
-            else hipLaunchKernelGGL((gemm128_f32_mfma_kernel<A_MK, B_NK, EPI, 128>), grid, dim3(256), lds, st, G);
+            typedef std::integral_constant<int, EPI> epi_t;
+            if (int rc = narrow ? launch128(epi_t{}, tn64_t{}, G) : launch128(epi_t{}, tn128_t{}, G)) return rc;
             if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;

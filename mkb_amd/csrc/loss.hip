@@ -51,12 +51,18 @@ __device__ __forceinline__ float fast_log_sigmoid(float z) {  // min(z,0) - log1
 }
 __device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.f + fast_exp(-z)); }
 
-// one wave per row; rowpart[i] = w_i * (ps_i + ns_i).  Rows of up to 64 * kRowRegs columns are read ONCE into registers
-// (the three passes -- max, partition sums, gradient seeds -- then run on registers); longer rows re-read global memory.
+// one wave per row; rowpart[i] = w_i * (ps_i + ns_i).
+// Columns are handled 64 at a time (column group t: lane l owns column l + 64 t).  Rows of up to kStageCols columns are read
+// from global memory ONCE and staged in LDS -- scores in s_v, multiplicities (then softmax numerators) in s_e, both
+// [column][rows + 1] words, so the 64 lanes of a group hit 64 different banks -- and the three passes (max, partition sums,
+// gradient seeds) are LOOPS over the column groups.  (Round 3 kept the row in registers instead, which needs every pass fully
+// unrolled over 16 groups x up to 16 split partials: 42 KB of straight-line code of which a wave executed ~9 KB once -- and
+// per-launch code is paid per byte, the instruction cache is cold at every launch: DESIGN.md section 8.  The loads are issued
+// four groups at a time, so a row still costs only two or three round trips.)  Longer rows re-read global memory.
 // TILE (tile-blocked seed layout only): 512 lanes = the 8 rows of one row tile.  Written straight from the rows, the
 // seeds of one row are 4-byte stores 2 KB apart (512 k partial-line writes per 1024 rows: the kernel's duration grew
-// linearly with the rows, 12 -> 41 us from 1024 to 8192); staged through LDS the tile goes out as whole 2 KB runs.
-constexpr int kRowRegs = 16;
+// linearly with the rows, 12 -> 41 us from 1024 to 8192); staged through LDS (s_v itself) the tile goes out as whole 2 KB runs.
+constexpr int kStageCols = 1024;
 template <bool TILE>
 __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(const float *__restrict__ pos, const float *__restrict__ neg,
                                                                const float *__restrict__ w, const uint16_t *__restrict__ cnt,
@@ -66,12 +72,15 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
                                                                GemmTail NT,
                                                                int *__restrict__ occ, const int64_t *__restrict__ occ_sample,
                                                                const int64_t *__restrict__ occ_pool) {
-    constexpr int NTH = TILE ? 512 : 256, RPB = NTH / 64;  // lanes and rows per workgroup
+    constexpr int NTH = TILE ? 512 : 256, RPB = NTH / 64, RS = RPB + 1;  // lanes and rows per workgroup, LDS words per column
     __shared__ float red[4];
-    extern __shared__ float s_seed[];  // TILE: [cap positions][9] (8 rows + 1 pad), cap = blocks * halves * 64
-    const int cap = TILE ? (64 << (SL.log2_blocks + SL.log2_halves)) : 0;
+    extern __shared__ float s_dyn[];
+    const int cap = TILE ? (64 << (SL.log2_blocks + SL.log2_halves)) : 0;  // TILE: positions of the blocked layout (>= K)
+    const bool staged = K <= kStageCols;
+    float *s_v = s_dyn;                                  // TILE: [cap][9] (also the seed tile that goes out), else [K][5]
+    float *s_e = s_dyn + (size_t)(TILE ? cap : K) * RS;  // [K][RS] (staged rows only)
     if constexpr (TILE) {
-        for (int e = threadIdx.x; e < cap * 9; e += NTH) s_seed[e] = 0.f;  // (padding slots and rows past the batch stay 0)
+        for (int e = threadIdx.x; e < cap * RS; e += NTH) s_v[e] = 0.f;  // (padding slots and rows past the batch stay 0)
         __syncthreads();
     }
     if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
@@ -82,88 +91,84 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
             for (int64_t p = row; p < K; p += B) atomicAdd(occ + occ_pool[p], 1);
         }
     }
-    const int lane = threadIdx.x & 63;
-    const int i_raw = blockIdx.x * RPB + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int i_raw = blockIdx.x * RPB + r;
     const int i = min(i_raw, B - 1);  // (rows past the batch load row B-1 and leave after the workgroup-wide W reduction)
+    const bool live = i_raw < B;
     const float *nrow = neg + (int64_t)i * K;
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
-    const bool in_regs = K <= 64 * kRowRegs;
-    float v[kRowRegs], c[kRowRegs];
-    if (in_regs && NT.kind == 3) {  // dense prefix of the scores still in the forward tile's dim-split partials [z][B][N]
+    const int nt = (K + 63) >> 6;
+    float m = -INFINITY;
+    if (staged) {
+        // scores still in split partials are reduced here, in the order of splitk_reduce_kernel (fixed: deterministic):
+        //   kind 1: every column, part[z * n + i * K + j];  kind 3: columns < N (the forward tile's dense prefix), part[z][i][j]
+        for (int t0 = 0; t0 < nt; t0 += 4) {
+            float cc[4], pz[4][8];
 #pragma unroll
-        for (int t = 0; t < kRowRegs; ++t) {
-            const int j = lane + 64 * t;
-            const bool ok = j < K;
-            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
-            if (ok && j < NT.N) {
-                // <= 16 splits: all their loads issued together (a run-time trip count made them one round trip each)
-                const float *pp = NT.part + (int64_t)i * NT.N + j;
-                float pz[16];
+            for (int u = 0; u < 4; ++u) {  // the loads of four column groups are issued together
+                const int t = t0 + u, j = lane + 64 * t, jc = min(j, K - 1);
+                cc[u] = crow ? (float)crow[jc] : 1.f;
+                const bool split = NT.kind == 1 || (NT.kind == 3 && 64 * t < NT.N);  // (wave-uniform: N is a multiple of 64)
+                if (split) {
+                    const float *pp = NT.kind == 1 ? NT.part + (int64_t)i * K + jc : NT.part + (int64_t)i * NT.N + min(j, NT.N - 1);
 #pragma unroll
-                for (int z = 0; z < 16; ++z) pz[z] = pp[(int64_t)min(z, NT.nz - 1) * NT.n];
-                float acc = 0.f;
-#pragma unroll
-                for (int z = 0; z < 16; ++z) acc += z < NT.nz ? pz[z] : 0.f;  // fixed order: deterministic
-                v[t] = c[t] > 0.f ? NT.c0 + NT.c1 * acc : 0.f;  // (pairs the row does not use were computed: defined as 0)
-                NT.out[(int64_t)i * K + j] = v[t];
-            } else {
-                v[t] = ok ? nrow[j] : 0.f;  // the fringe: finished scores
+                    for (int z = 0; z < 8; ++z) pz[u][z] = pp[(int64_t)min(z, NT.nz - 1) * NT.n];
+                } else {
+                    pz[u][0] = nrow[jc];
+                }
             }
-        }
-    } else if (in_regs && NT.kind != 1) {  // (one straight run of loads: a branch inside this loop serialises their latencies)
 #pragma unroll
-        for (int t = 0; t < kRowRegs; ++t) {
-            const int j = lane + 64 * t;
-            const bool ok = j < K;
-            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
-            v[t] = ok ? nrow[j] : 0.f;
-        }
-    } else if (in_regs) {  // scores still in split-K partials: reduce them here (same order as splitk_reduce_kernel)
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u, j = lane + 64 * t;
+                const bool ok = j < K;
+                const bool split = NT.kind == 1 || (NT.kind == 3 && 64 * t < NT.N);
+                const float c = ok ? cc[u] : 0.f;
+                float v = pz[u][0];
+                if (split) {
+                    float acc = 0.f;
 #pragma unroll
-        for (int t = 0; t < kRowRegs; ++t) {
-            const int j = lane + 64 * t;
-            const bool ok = j < K;
-            c[t] = ok ? (crow ? (float)crow[j] : 1.f) : 0.f;
-            float acc = 0.f;
-            if (ok) {  // <= 8 splits: their loads issued together (a run-time trip count made them one round trip each)
-                const float *pp = NT.part + (int64_t)i * K + j;
-                float pz[8];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) pz[z] = pp[(int64_t)min(z, NT.nz - 1) * NT.n];
-#pragma unroll
-                for (int z = 0; z < 8; ++z) acc += z < NT.nz ? pz[z] : 0.f;  // fixed order: deterministic
+                    for (int z = 0; z < 8; ++z) acc += z < NT.nz ? pz[u][z] : 0.f;
+                    if (NT.nz > 8) {  // (up to 16 splits: the second eight, same order)
+                        const float *pp = NT.kind == 1 ? NT.part + (int64_t)i * K + min(j, K - 1) : NT.part + (int64_t)i * NT.N + min(j, NT.N - 1);
+                        for (int z = 8; z < NT.nz; ++z) acc += pp[(int64_t)z * NT.n];
+                    }
+                    v = NT.c0 + NT.c1 * acc;
+                    if (NT.kind == 3) v = c > 0.f ? v : 0.f;  // (pairs the row does not use were computed: defined as 0)
+                    if (ok) NT.out[(int64_t)i * K + j] = v;
+                }
+                v = ok ? v : 0.f;
+                if (ok && live) {
+                    s_v[j * RS + r] = v;
+                    s_e[j * RS + r] = c;
+                }
+                if (c > 0.f) m = fmaxf(m, alpha * v);
             }
-            v[t] = ok ? NT.c0 + NT.c1 * acc : 0.f;
-            if (ok) NT.out[(int64_t)i * K + j] = v[t];
         }
     }
     // scal == nullptr: W is reduced here, by every workgroup alike (its loads and barriers run under the row's loads, which
     // were issued above); workgroup 0 publishes it for the finish step
     const float W = scal ? scal[0] : weight_sum_block(w, B, red);
     if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
-    const bool live = i_raw < B;
     if (!TILE && !live) return;
     if (live) {
-    float m = -INFINITY;
-    if (in_regs) {
-#pragma unroll
-        for (int t = 0; t < kRowRegs; ++t)
-            if (c[t] > 0.f) m = fmaxf(m, alpha * v[t]);
-    } else {
+    if (!staged) {
         for (int j = lane; j < K; j += 64)
             if (!crow || crow[j]) m = fmaxf(m, alpha * nrow[j]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     float z = 0.f, s = 0.f;
-    if (in_regs) {
-#pragma unroll
-        for (int t = 0; t < kRowRegs; ++t) {
-            if (c[t] > 0.f) {
-                const float e = c[t] * fast_exp(alpha * v[t] - m);
+    if (staged) {
+#pragma unroll 2
+        for (int t = 0; t < nt; ++t) {
+            const int j = lane + 64 * t;
+            const float c = j < K ? s_e[j * RS + r] : 0.f;
+            if (c > 0.f) {
+                const float v = s_v[j * RS + r];
+                const float e = c * fast_exp(alpha * v - m);
                 z += e;
-                s += e * fast_log_sigmoid(-v[t]);
-                c[t] = e;  // keep the softmax numerator for the gradient pass
+                s += e * fast_log_sigmoid(-v);
+                s_e[j * RS + r] = e;  // keep the softmax numerator for the gradient pass
             }
         }
     } else {
@@ -182,13 +187,14 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     const float wi = w[i];
     const float coef = 0.5f * wi / W;
     const float invz = 1.f / z;
-    if (in_regs) {
-#pragma unroll
-        for (int t = 0; t < kRowRegs; ++t) {
+    if (staged) {
+#pragma unroll 2
+        for (int t = 0; t < nt; ++t) {
             const int j = lane + 64 * t;
             if (j < K) {
-                const float g = c[t] > 0.f ? coef * (c[t] * invz) * fast_sigmoid(v[t]) : 0.f;
-                if constexpr (TILE) s_seed[j * 9 + (i & 7)] = g;
+                const float e = s_e[j * RS + r];
+                const float g = e > 0.f ? coef * (e * invz) * fast_sigmoid(s_v[j * RS + r]) : 0.f;
+                if constexpr (TILE) s_v[j * RS + r] = g;
                 else dneg[seed_index(SL, i, j, K)] = g;
             }
         }
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
                 const float vv = nrow[j];
                 g = coef * (cc * fast_exp(alpha * vv - m) * invz) * fast_sigmoid(vv);
             }
-            if constexpr (TILE) s_seed[j * 9 + (i & 7)] = g;
+            if constexpr (TILE) s_v[j * RS + r] = g;
             else dneg[seed_index(SL, i, j, K)] = g;
         }
     }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
             const int run = q >> 7, off = (q & 127) * 4, l = off >> 3, r0 = off & 7;
             const int pb = run >> SL.log2_halves, h = run & (halves - 1);
             const int p = pb + blocks * (l * halves + h);
-            const float *src = s_seed + p * 9 + r0;
+            const float *src = s_v + p * RS + r0;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p < cap) o = make_float4(src[0], src[1], src[2], src[3]);
             *reinterpret_cast<float4 *>(tile_out + (int64_t)q * 4) = o;
@@ -241,7 +247,7 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
     float *scal = scratch, *rowpart = scratch + 1;
     GemmTail nt{};
     if (neg_tail && (neg_tail->kind == 1 || neg_tail->kind == 3)) {
-        if (K > 64 * kRowRegs) return set_error(MKB_ERR_INVALID, "split-K scores can only ride rows of <= %d columns", 64 * kRowRegs);
+        if (K > kStageCols) return set_error(MKB_ERR_INVALID, "split-K scores can only ride rows of <= %d columns", kStageCols);
         nt = *neg_tail;
     }
     const float *scal_in = weight_sum;  // W of the whole (sharded) batch when the caller supplies it
@@ -253,13 +259,16 @@ int adversarial_launch(const float *pos, const float *neg, const float *weight, 
     if (seeds.log2_blocks >= 0) {  // tile-blocked seeds: one row tile per 512-lane workgroup, staged through LDS
         const int cap = 64 << (seeds.log2_blocks + seeds.log2_halves);
         if (cap < K) return set_error(MKB_ERR_INVALID, "blocked seed layout holds %d positions, the rows have %d", cap, (int)K);
-        static LdsOptIn lds_ok;  // pools of more than ~1800 positions stage more than 64 KB of seeds: opt in once per device
-        if (int rc = lds_ok.ensure(reinterpret_cast<const void *>(&adversarial_rows_kernel<true>), (size_t)cap * 9 * 4)) return rc;
-        hipLaunchKernelGGL(adversarial_rows_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(512), (size_t)cap * 9 * 4, st, pos, neg,
+        // LDS: the seed tile [cap][9] (which first holds the scores) + the multiplicities [K][9] of rows short enough to stage
+        const size_t lds = ((size_t)cap + (K <= kStageCols ? (size_t)K : 0)) * 9 * 4;
+        static LdsOptIn lds_ok;  // more than 64 KB (pools of ~1000 positions and up): opt in once per device
+        if (int rc = lds_ok.ensure(reinterpret_cast<const void *>(&adversarial_rows_kernel<true>), lds)) return rc;
+        hipLaunchKernelGGL(adversarial_rows_kernel<true>, dim3((unsigned)((B + 7) / 8)), dim3(512), lds, st, pos, neg,
                            weight, cnt, (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, occ,
                            occ_sample, occ_pool);
     } else {
-        hipLaunchKernelGGL(adversarial_rows_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, pos, neg, weight, cnt,
+        const size_t lds = K <= kStageCols ? (size_t)K * 5 * 4 * 2 : 0;  // scores + multiplicities [K][5] of staged rows
+        hipLaunchKernelGGL(adversarial_rows_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), lds, st, pos, neg, weight, cnt,
                            (int)B, (int)K, alpha, scal_in, scal, dpos, dneg, rowpart, seeds, nt, occ, occ_sample,
                            occ_pool);
     }

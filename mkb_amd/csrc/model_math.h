@@ -25,6 +25,29 @@ template <> struct ModelTraits<MKB_ROTATE>   { static constexpr bool cplx_query 
 
 struct Cplx { float re, im; };
 
+// sin and cos of one argument in ~25 VALU instructions: Cody-Waite reduction by pi/2 (three constants whose products with the
+// quadrant number are exact) + the Cephes single-precision polynomials on [-pi/4, pi/4].  Max abs error 9.2e-8 for
+// |x| <= 1e5 (libm's sinf / cosf: 7e-8; checked over 2 M points per range in numpy), growing like |x| * 6e-8 beyond that --
+// the arguments here are phases r / (range / pi) or (h + r - t) / (range / pi) of table entries, O(pi).  libm's sinf + cosf
+// inline ~200 instructions EACH with their large-argument paths; they sat in every row kernel (per-launch code is paid per
+// byte: the instruction cache is cold at every launch) and, unrolled per pair term, made pRotatE's pooled kernels 6 MB of
+// the library.  NaN / Inf give NaN like libm.
+__device__ __forceinline__ void sincos_f32(float x, float &s, float &c) {
+    const float q = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-q, 1.5703125f, x);
+    r = fmaf(-q, 4.837512969970703125e-4f, r);
+    r = fmaf(-q, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int n = (int)q;
+    const float a = (n & 1) ? pc : ps, b = (n & 1) ? ps : pc;  // quadrant: sin, cos swap in the odd ones
+    s = (n & 2) ? -a : a;
+    c = ((n + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ float sin_f32(float x) { float s, c; sincos_f32(x, s, c); return s; }
+
 // ---------------------------------------------------------------- query build (real models)
 // a, b = the two fixed operands: tail-style (h, r), head-style (r, t).
 template <int MODEL, bool HEAD>
@@ -42,9 +65,7 @@ template <int MODEL, bool HEAD>
 __device__ __forceinline__ Cplx build_q_cplx(Cplx e, Cplx r, float kd) {
     float c, s;
     if constexpr (MODEL == MKB_ROTATE) {
-        const float phase = r.re / kd;
-        c = cosf(phase);
-        s = sinf(phase);
+        sincos_f32(r.re / kd, s, c);
     } else {
         c = r.re;
         s = r.im;
@@ -65,7 +86,7 @@ template <int MODEL, bool HEAD>
 __device__ __forceinline__ float pair_term_real(float q, float x, float kd) {
     if constexpr (MODEL == MKB_TRANSE) return fabsf(HEAD ? (x + q) : (q - x));
     if constexpr (MODEL == MKB_DISTMULT || MODEL == MKB_COMPLEX) return q * x;
-    if constexpr (MODEL == MKB_PROTATE) return fabsf(sinf(HEAD ? (x / kd + q) : (q - x / kd)));
+    if constexpr (MODEL == MKB_PROTATE) return fabsf(sin_f32(HEAD ? (x / kd + q) : (q - x / kd)));
     return 0.f;
 }
 
@@ -99,9 +120,10 @@ __device__ __forceinline__ void pair_bwd_real(float q, float x, float g, float k
         dx = g * q;
     } else if constexpr (MODEL == MKB_PROTATE) {
         const float z = HEAD ? (x / kd + q) : (q - x / kd);
-        const float sz = sinf(z);
+        float sz, cz;
+        sincos_f32(z, sz, cz);
         const float sg = (sz > 0.f) ? 1.f : ((sz < 0.f) ? -1.f : 0.f);
-        const float c = cosf(z) * sg * modulus;
+        const float c = cz * sg * modulus;
         dq = -g * c;
         dx = (HEAD ? (-g * c) : (g * c)) / kd;
         extra += fabsf(sz);
@@ -192,9 +214,7 @@ template <int MODEL, bool HEAD>
 __device__ __forceinline__ void query_bwd_cplx(Cplx e, Cplx r, Cplx dq, float kd, Cplx &de, Cplx &dr) {
     float c, s;
     if constexpr (MODEL == MKB_ROTATE) {
-        const float phase = r.re / kd;
-        c = cosf(phase);
-        s = sinf(phase);
+        sincos_f32(r.re / kd, s, c);
     } else {
         c = r.re;
         s = r.im;

@@ -133,6 +133,12 @@ struct RowStepArgs {
     const uint16_t *cnt;
     int *depth;
     int depth_P;
+    // (Round 4 tried 16 bytes per lane with every load of a row issued before the first use -- 125 VGPRs, half the resident
+    // waves, atomics at stride 16: row_bwd 29 -> 53 us at the headline shape.  The row kernels are bound by bytes and by
+    // the L2 atomic units, not by the latency of their loads: 32 waves per CU hide that.  Removed.)
+    // row_bwd: the gradient rows this step writes are known to be all-zero (the row-lazy optimizer's advance launch consumed
+    // and cleared them): rows written by exactly one workgroup are STORED, not read-modified-written
+    int grads_clear;
 };
 
 __device__ __forceinline__ float block_sum_256_row(float v, float *red) {
@@ -209,8 +215,11 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     const int64_t sstride = (int64_t)A.B * A.De;
     const float gp = A.dpos[i];
     const bool own_h = A.occ && A.occ[h] == 1, own_t = A.occ && A.occ[t] == 1;  // workgroup-uniform
-    auto add_h = [&](int k, float v) { if (own_h) g_h[k] += v; else atomicAdd(g_h + k, v); };
-    auto add_t = [&](int k, float v) { if (own_t) g_t[k] += v; else atomicAdd(g_t + k, v); };
+    // rows one workgroup alone writes: a plain store when the row is known to be all-zero (grads_clear), else read-modify-
+    // write; shared rows: one fp32 atomic per element
+    const bool st_h = own_h && A.grads_clear, st_t = own_t && A.grads_clear;  // workgroup-uniform
+    auto add_h = [&](int k, float v) { if (st_h) g_h[k] = v; else if (own_h) g_h[k] += v; else atomicAdd(g_h + k, v); };
+    auto add_t = [&](int k, float v) { if (st_t) g_t[k] = v; else if (own_t) g_t[k] += v; else atomicAdd(g_t + k, v); };
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
     auto dq_at = [&](int k) {
         float s = 0.f;
@@ -336,8 +345,9 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     const bool even2 = al16 && NU % 2 == 0 && De % 2 == 0 && (!cp || d % 2 == 0);
     const bool even4 = al16 && NU % 4 == 0 && De % 4 == 0 && (!cp || d % 4 == 0);
     // units per lane: vector loads + packed math need even dims; waves: smallest workgroup that covers the row
+    const bool k4 = even4 && tb->model != MKB_PROTATE;  // (pRotatE: no 4-units-per-lane instantiations, see launch_head)
     if (even2 && NU >= 64 && NU <= 2048) L.kpt = 2;
-    else if (even4 && NU > 2048 && NU <= 4096) L.kpt = 4;
+    else if (k4 && NU > 2048 && NU <= 4096) L.kpt = 4;
     else if (NU <= 1024) L.kpt = 1;
     else return false;
     const int lanes = (NU + L.kpt - 1) / L.kpt;
@@ -353,7 +363,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     // forward: 4 units per lane when the row allows it (measured 91 -> 77 us at the headline shape: the per-position
     // wave reduction is amortised over twice the pair evaluations); the backward kernels gain nothing from it
     L.fkpt = L.kpt; L.fnw = L.nw;
-    if (even4 && NU > 512 && NU <= 1024) { L.fkpt = 4; L.fnw = 4; }
+    if (k4 && NU > 512 && NU <= 1024) { L.fkpt = 4; L.fnw = 4; }
     // Forward of the complex-modulus models: dense prefix [0, Kd) of the pool on the outer-product register tile, the sparse
     // fringe on the row-tile kernel in the same launch (score_pool_tile.h).  Needs the 4-wave forward configuration (rows of
     // 257 .. 1024 complex dims), whole 64-position tiles in the prefix (K = P / 2 >= 64) and 16-byte rows.
@@ -401,7 +411,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
         // units per lane of the single-pass backward: 2 (1 for odd rows); real-valued models with long rows take 4 -- the
         // same 4 floats per lane and position as RotatE's two complex dims, half the per-position bookkeeping of 2
         static const bool no_k4 = getenv("MKB_POOL_BWD1_NO_K4") != nullptr;  // A/B switch
-        const int k1 = (!cp && even4 && NU >= 512 && !no_k4) ? 4 : (L.kpt >= 2 ? 2 : 1), nc = k1 * (cp ? 2 : 1);
+        const int k1 = (!cp && k4 && NU >= 512 && !no_k4) ? 4 : (L.kpt >= 2 ? 2 : 1), nc = k1 * (cp ? 2 : 1);
         L.bkpt = k1;
         const int lanes1 = (NU + k1 - 1) / k1;
         L.dim_slices = (lanes1 + 63) / 64;
@@ -779,6 +789,8 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr,
                             no_fold ? nullptr : &ra.sc)) return rc;
     ra.dx.occ = ra.occ;  // (the dx reduction riding this launch writes pool rows: exclusive ones without atomics)
+    ra.grads_clear = gr->rows_clear ? 1 : 0;
+    ra.dx.clear = ra.grads_clear;
     ProfScope ps(MKB_PROF_GENERAL_BWD, st);
     if (int rc = dispatch_row_bwd(tb, head, ra, B, st)) return rc;
     if (ra.rel_rep) {

@@ -894,6 +894,10 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(gL)::"memory");
             };
+            // (Round 4 looked at the ISA of this loop: per position the wave stops three times -- an s_waitcnt lgkmcnt(1) two
+            // instructions into the body, lgkmcnt(0) before the accumulator add, lgkmcnt(0) behind the write.  Issuing the three LDS
+            // operations by hand so that only the middle one remains was tried and dropped: the extra live registers pushed
+            // the loop into scratch spills -- the kernel sits at 126 of 128 VGPRs -- and the first wait stayed.)
             acc_t xv_n = acc_t{};         // the next position's row image
             int slot_n = 0, dslot_n = 0;  // the current position's slots
             int ph1 = 0, k1 = 0;          // the position after the current one (its seeds are requested a position ahead)
@@ -1504,6 +1508,7 @@ struct DxReduce {
     int P, d, npb, halves, dim_slices, row_groups, kpt, cplx;
     int blocks;  // npb * halves * 64
     const int *occ;  // rider of the row backward: occurrence counts of the batch's entities (RowStepArgs::occ), or null
+    int clear;       // the gradient rows are known to be all-zero (mkb_grads_t::rows_clear): exclusive rows are stored, not added to
 };
 
 __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int block) {
@@ -1512,29 +1517,60 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
     const int h = sidx >> 6, l = sidx & 63;
     const int p = pb + R.npb * (l * R.halves + h);
     if (p >= R.P) return;
-    bool any = false;  // did any row group use the slot?
-    for (int rg = 0; rg < R.row_groups; ++rg) any |= ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
-    if (!any) return;
+    // which row groups used the slot: lane rg reads the mask of row group rg (all loads at once), a ballot collects them
+    unsigned long long used_rg = 0ull;
+    for (int rg0 = 0; rg0 < R.row_groups; rg0 += 64) {
+        const int rg = rg0 + (int)(threadIdx.x & 63);
+        const bool u = rg < R.row_groups && ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
+        const unsigned long long b = __ballot(u);
+        if (rg0 == 0) used_rg = b;
+        else if (b) used_rg |= 1ull << 63;  // (more than 64 row groups: "somebody beyond the first 64"; the loops below re-read)
+    }
+    if (!used_rg) return;
     const int nc = R.kpt * (R.cplx ? 2 : 1), NU = R.cplx ? R.d : (int)R.De;
     const int64_t ent = R.pool[p];
     float *row = R.g_ent + ent * R.De;
     // an entity that occurs once among the batch's pool ids, heads and tails: nobody else writes its gradient row in this
-    // launch -> plain read-modify-write (workgroup-uniform)
+    // launch -> plain read-modify-write (workgroup-uniform), or a plain store when the row is known to be zero
     const bool own = R.occ && R.occ[ent] == 1;
-    auto add = [&](float *dst, float v) { if (own) *dst += v; else atomicAdd(dst, v); };
+    const bool store = own && R.clear;
+    auto add = [&](float *dst, float v) { if (store) *dst = v; else if (own) *dst += v; else atomicAdd(dst, v); };
     const int per_slot = R.dim_slices * 64 * nc;  // floats of one slot of one row group
     if (nc == 4 && R.cplx) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
         for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
             const int u = e * 2;
             if (u >= NU) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int rg = 0; rg < R.row_groups; ++rg) {
-                if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
-                const float4 v = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            // eight row groups at a time: their partial rows are requested together (a loop with a run-time trip count and a
+            // skip inside made every row group its own round trip), added in row-group order
+            for (int rg0 = 0; rg0 < R.row_groups; rg0 += 8) {
+                float4 v[8];
+                bool on[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rg = rg0 + k;
+                    on[k] = rg < R.row_groups && (rg < 63 ? ((used_rg >> rg) & 1ull) != 0ull
+                                                          : ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull);
+                    const int rgc = on[k] ? rg : 0;  // (row group 0's partial buffer always exists: a harmless address)
+                    v[k] = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rgc * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (on[k]) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
             }
-            add(row + u, a.x); add(row + u + 1, a.y);
-            add(row + R.d + u, a.z); add(row + R.d + u + 1, a.w);
+            // (u is even and NU = d a multiple of 2 on this path: [re0 re1] and [im0 im1] are 8-byte pairs)
+            if (own) {
+                float2 *pr = reinterpret_cast<float2 *>(row + u), *pi = reinterpret_cast<float2 *>(row + R.d + u);
+                if (store) { *pr = make_float2(a.x, a.y); *pi = make_float2(a.z, a.w); }
+                else {
+                    const float2 o0 = *pr, o1 = *pi;
+                    *pr = make_float2(o0.x + a.x, o0.y + a.y);
+                    *pi = make_float2(o1.x + a.z, o1.y + a.w);
+                }
+            } else {
+                atomicAdd(row + u, a.x); atomicAdd(row + u + 1, a.y);
+                atomicAdd(row + R.d + u, a.z); atomicAdd(row + R.d + u + 1, a.w);
+            }
         }
         return;
     }
@@ -1654,7 +1690,7 @@ template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
     if (which == 5) return launch_fwd_tile<MODEL, HEAD>(L0, A, st, A.tile_part, A.tile_tail);
     if (which == 4) {
-        if constexpr (!ModelTraits<MODEL>::cplx_pair)
+        if constexpr (!ModelTraits<MODEL>::cplx_pair && MODEL != MKB_PROTATE)
             if (L0.bkpt == 4) return launch_bwd1<MODEL, HEAD, 4>(L0, A, st);
         return L0.bkpt >= 2 ? launch_bwd1<MODEL, HEAD, 2>(L0, A, st) : launch_bwd1<MODEL, HEAD, 1>(L0, A, st);
     }
@@ -1669,8 +1705,12 @@ static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipSt
     if (L.kpt == 2 && L.nw == 4) return launch_cfg<MODEL, HEAD, 2, 4>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 8) return launch_cfg<MODEL, HEAD, 2, 8>(which, L, A, st);
     if (L.kpt == 2 && L.nw == 16) return launch_cfg<MODEL, HEAD, 2, 16>(which, L, A, st);
-    if (L.kpt == 4 && L.nw == 4) return launch_cfg<MODEL, HEAD, 4, 4>(which, L, A, st);
-    if (L.kpt == 4 && L.nw == 16) return launch_cfg<MODEL, HEAD, 4, 16>(which, L, A, st);
+    // (pRotatE's pair term carries a sin / cos and two divisions: its 4-units-per-lane bodies are 230 KB of code each and
+    // were a seventh of the library; pick_config keeps that model at <= 2 units per lane)
+    if constexpr (MODEL != MKB_PROTATE) {
+        if (L.kpt == 4 && L.nw == 4) return launch_cfg<MODEL, HEAD, 4, 4>(which, L, A, st);
+        if (L.kpt == 4 && L.nw == 16) return launch_cfg<MODEL, HEAD, 4, 16>(which, L, A, st);
+    }
     return set_error(MKB_ERR_UNSUPPORTED, "no pooled kernel configuration (kpt=%d, nw=%d)", L.kpt, L.nw);
 }
 

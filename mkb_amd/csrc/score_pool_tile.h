@@ -23,6 +23,9 @@
 namespace mkb {
 
 constexpr int kTileKC = 16;                     // dims per LDS chunk
+#ifndef MKB_TILE_UNROLL
+#define MKB_TILE_UNROLL 1
+#endif
 constexpr int kTileRows = 64, kTilePos = 64;    // workgroup tile (2 x 2 waves of 32 x 32)
 constexpr int kTilePitch = kTileRows * 4 + 4;   // floats per k-pair row of the LDS image (+ 16 B pad)
 
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
     for (int k0 = k_lo; k0 < k_hi; k0 += kTileKC) {
         const bool more = k0 + kTileKC < k_hi;
         if (more) gload(k0 + kTileKC);  // the next chunk's global loads fly under this chunk's pair math
-#pragma unroll 1
+#pragma unroll MKB_TILE_UNROLL
         for (int kp = 0; kp < kTileKC / 2; ++kp) {
             float4 q[4], x[4];
 #pragma unroll

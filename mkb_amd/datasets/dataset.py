@@ -36,6 +36,33 @@ def _first_seen(labels):
     return index
 
 
+class _IndexBatches:
+    """``BatchSampler(RandomSampler(view) | SequentialSampler(view), batch_size, drop_last=False)`` as ONE object that hands
+    out whole index arrays.  torch's pair walks the permutation index by index through two Python generators (0.6 ms per
+    1024-row batch -- more than two MI355X training steps); this one slices the same permutation.  Same draws from the
+    global generator at the same moments as ``RandomSampler.__iter__`` (torch/utils/data/sampler.py): the shuffle seed is
+    taken when the first batch is asked for, then ONE ``randperm(n)`` from a private generator seeded with it."""
+
+    def __init__(self, n, batch_size, shuffle):
+        self.n, self.batch_size, self.shuffle = n, batch_size, shuffle
+
+    def __len__(self):
+        return -(-self.n // self.batch_size)
+
+    def __iter__(self):
+        if self.shuffle:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            generator = torch.Generator()
+            generator.manual_seed(seed)
+            order = torch.randperm(self.n, generator=generator).numpy()
+        else:
+            import numpy as np
+
+            order = np.arange(self.n, dtype=np.int64)
+        for lo in range(0, self.n, self.batch_size):
+            yield order[lo: lo + self.batch_size]
+
+
 class Dataset:
     def __init__(self, train, batch_size, entities=None, relations=None, valid=None, test=None, shuffle=True,
                  classification=False, pre_compute=True, num_workers=1, seed=42, classification_valid=None,
@@ -102,14 +129,44 @@ class Dataset:
         return self._streams["tail-batch"]
 
     def get_train_loader(self, mode):
+        """The reference's loader (dataset.py:297-303) for one training view.  ``num_workers`` worker PROCESSES are not
+        started: a batch is one indexed read here (``TrainDataset.__getitems__``, ~0.1 ms), and shipping it through a worker's
+        queue costs ~2 ms -- eight MI355X training steps.  The batches and their order are those of the worker-process
+        loader: the index sampler runs in the main process either way, and ``__iter__`` draws the two views' shuffle seeds in
+        the order a worker-process loader draws them (``tests/test_gpu_pool.py::test_pipeline_countries_vs_reference_capture``
+        replays the reference's own batches)."""
         view = TrainDataset(triples=self.train, entities=self.entities, relations=self.relations, mode=mode,
                             pre_compute=self.pre_compute, seed=self.seed)
-        return data.DataLoader(view, batch_size=self.batch_size, shuffle=self.shuffle, num_workers=self.num_workers,
+        return data.DataLoader(view, batch_sampler=_IndexBatches(len(view), self.batch_size, self.shuffle), num_workers=0,
                                collate_fn=TrainDataset.collate_fn)
 
     def __iter__(self):
-        # zip() stops with the shorter view; chain.from_iterable flattens each (head, tail) pair in that order
-        return itertools.chain.from_iterable(zip(*(self._loaders[mode] for mode in _VIEWS)))
+        """head-batch, tail-batch, head-batch ... until the shorter view ends (the reference zips its two loaders,
+        dataset.py:196-203).  A loader with worker processes draws its base seed AND -- by prefetching -- its sampler's shuffle
+        seed from the global generator when its iterator is created, so the reference consumes the generator in the order
+        head(base, shuffle), tail(base, shuffle); an in-process loader would draw the shuffle seed at the first ``next``.  Taking
+        each view's first batch right after creating its iterator reproduces the reference's order exactly."""
+        if self.num_workers == 0:  # the caller asked for in-process loaders: torch's own order for those
+            yield from itertools.chain.from_iterable(zip(*(self._loaders[mode] for mode in _VIEWS)))
+            return
+        end = object()
+        iters, firsts = [], []
+        for mode in _VIEWS:
+            it = iter(self._loaders[mode])
+            iters.append(it)
+            firsts.append(next(it, end))
+        while True:
+            if any(b is end for b in firsts):  # zip() semantics: stop with the shorter view
+                return
+            yield from firsts
+            firsts = []
+            for it in iters:
+                b = next(it, end)
+                firsts.append(b)
+                if b is end:
+                    break
+            while len(firsts) < len(iters):
+                firsts.append(end)
 
     def __next__(self):
         self.step = step = self.step + 1

@@ -134,9 +134,16 @@ class FusedTrainStep:
         lazy = _links.owner(ent)
         if lazy is not None:  # row-lazy Adam: the rows this step reads must be current before the forward pass
             ids = info.touched if info.touched is not None else torch.cat([info.pool, sample[:, 0], sample[:, 2]])
-            done = lazy._state(ent).get("caught_up")
-            if done is None or done[0] is not ids or done[1] != lazy._state(ent)["n"]:  # (sampled() already did it)
+            st = lazy._state(ent)
+            done = st.get("caught_up")
+            if done is None or done[0] is not ids or done[1] != st["n"]:  # (sampled() already did it)
                 lazy.catch_up(ent, ids)
+            # Deferred real step: that launch consumed AND cleared the gradient row of every row it visited (= every entity row
+            # this step writes), so unless an earlier backward of this same optimizer step has written since, those rows are
+            # all-zero: the row kernels may store instead of read-modify-write (mkb_grads_t.rows_clear)
+            if (st.get("defer") and st["n"] >= 1 and _links.touched(ent) is None and st.get("g") is not None
+                    and st["g"].data_ptr() == ent.grad.data_ptr()):
+                gr.rows_clear = 1
             _links.mark_touched(ent, ids)  # accumulates when several steps share one optimizer.step()
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),

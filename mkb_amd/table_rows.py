@@ -427,7 +427,8 @@ class TableRowShardedStep:
         pos = torch.empty((b, 1), dtype=torch.float32, device=dev)
         S = torch.empty((b, P), dtype=torch.float32, device=dev)
         ws = _workspace(m, b, K)
-        gr = _hip.Grads(bufs["grad"].data_ptr(), bufs["g_rel"].data_ptr(), bufs["g_mod"].data_ptr() if self._trains_modulus else None)
+        # (the compact gradient was cleared by this step's gather launch: every row the step writes starts from zero)
+        gr = _hip.Grads(bufs["grad"].data_ptr(), bufs["g_rel"].data_ptr(), bufs["g_mod"].data_ptr() if self._trains_modulus else None, 1)
         with torch.cuda.device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(compact), _hip.ptr(weight), _hip.ptr(bufs["pool_ids"]),
                                                 _hip.ptr(info.cnt), b, K, _hip.mode_id(mode), self.alpha, _hip.ptr(bufs["wsum"]),

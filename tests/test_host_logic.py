@@ -123,3 +123,35 @@ def test_test_dataset_items():
     assert n.tolist() == [0, 1, 2, 1, 4] and b.tolist() == [0, 0, 0, -100000.0, 0]   # (0,0,3)
     s, n, b, mode = TestDatasetRelation([(0, 0, 1)], true, ents, rels)[0]
     assert mode == "relation-batch" and n.tolist() == [[0, 0, 1], [0, 0, 1]] and b.tolist() == [0, -1]
+
+
+def test_in_process_train_loaders_yield_the_worker_process_order():
+    """datasets.Dataset builds its two training DataLoaders without worker processes (a batch is one indexed read:
+    TrainDataset.__getitems__) and still yields the batches of the reference's num_workers=1 loaders, in their order: a
+    worker-process loader draws base seed AND shuffle seed when its iterator is created, Dataset.__iter__ reproduces that."""
+    import itertools
+
+    import torch
+    from torch.utils import data
+
+    from mkb_amd import datasets
+    from mkb_amd.datasets.base import TrainDataset
+
+    def ours():
+        ds = datasets.CountriesS1(batch_size=20, seed=42)
+        return [(b["mode"], b["sample"].clone(), b["weight"].clone()) for _ in range(2) for b in ds]
+
+    def workers():
+        ds = datasets.CountriesS1(batch_size=20, seed=42)
+        views = {m: ds._loaders[m].dataset for m in ("head-batch", "tail-batch")}
+        for v in views.values():
+            v.__class__ = type("PerItem", (TrainDataset,), {"__getitems__": None})  # the reference's per-triple __getitem__ path
+        loaders = [data.DataLoader(views[m], batch_size=20, shuffle=True, num_workers=1, collate_fn=TrainDataset.collate_fn)
+                   for m in ("head-batch", "tail-batch")]
+        return [(b["mode"], b["sample"].clone(), b["weight"].clone()) for _ in range(2)
+                for b in itertools.chain.from_iterable(zip(*loaders))]
+
+    a, b = ours(), workers()
+    assert len(a) == len(b) > 0
+    for (ma, sa, wa), (mb, sb, wb) in zip(a, b):
+        assert ma == mb and torch.equal(sa, sb) and torch.equal(wa, wb)

@@ -230,3 +230,66 @@ def _private_gather_case(rank, world):
 
 def test_private_row_gather_and_gradient_return_world3():
     assert all(_run(_private_gather_case, world=3))
+
+
+def _plan_case(rank, world):
+    """Routes planned one batch ahead (mkb_amd.table_rows): a plan is keyed on the batch as the CALLER holds it, so a
+    non-contiguous view planned and then stepped hits the plan on every rank alike (the copy made for the kernels has another
+    address: that used to be a miss on that rank only -- one collective more than its peers: a hang); a step for ANOTHER batch
+    than the one planned raises on every rank instead of re-planning silently; drop_plan() discards a plan."""
+    from types import SimpleNamespace
+
+    from mkb_amd.table_rows import RowShardedTable, TableRowShardedStep
+    from oracle import scoring
+    from row_ops_torch import TorchRowOps
+
+    name, N, R, hidden, gamma, alpha, K = "TransE", 40, 3, 6, 6.0, 1.0, 4
+    B = 4 * world
+    torch.manual_seed(0)
+    full = scoring.init_tables(name, N, R, hidden, gamma)
+    g = torch.Generator().manual_seed(4)
+    calls = []
+
+    def compute(ent, rel, sample, weight, info, mode, weight_sum):
+        calls.append(1)
+        tb = scoring.Tables(name, hidden, gamma, ent, rel.detach(), full.modulus)
+        r = scoring.train_step_grads(tb, sample, info.pos.long(), weight, mode, alpha, fast_norm=True)
+        scale = weight.sum() / weight_sum
+        return r["loss"] * scale, r["g_ent"] * scale, r["g_rel"] * scale
+
+    table = RowShardedTable.from_full(full.ent, ops=TorchRowOps())
+    rel = torch.nn.Parameter(full.rel.clone())
+    step = TableRowShardedStep(table, rel, alpha, compute=compute)
+    wide = torch.stack([torch.randint(N, (3 * B,), generator=g), torch.randint(R, (3 * B,), generator=g),
+                        torch.randint(N, (3 * B,), generator=g), torch.zeros(3 * B, dtype=torch.int64)], 1)
+    pool = torch.randint(N, (2 * K,), generator=g)
+    pos = torch.stack([torch.randperm(2 * K, generator=g)[:K] for _ in range(B)])
+    cnt = torch.zeros(B, 2 * K, dtype=torch.int32).scatter_add_(1, pos, torch.ones_like(pos, dtype=torch.int32))
+    lo, hi = rank * B // world, (rank + 1) * B // world
+
+    def neg_of():
+        neg = pool[pos][lo:hi]
+        neg._mkb_pool = SimpleNamespace(pool=pool, pos=pos[lo:hi].to(torch.int32), cnt=cnt[lo:hi], size=K, mode_id=0)
+        return neg
+
+    w = torch.ones(hi - lo)
+    views = [wide[i * B + lo: i * B + hi, :3] for i in range(3)]   # NON-contiguous [b, 3] views of a [3B, 4] table
+    assert not views[0].is_contiguous()
+    step(views[0], w, neg_of(), "head-batch", next_sample=views[1])        # plans batch 1 while stepping batch 0
+    planned = step._plan is not None
+    step(wide[B + lo: B + hi, :3], w, neg_of(), "tail-batch")              # a fresh view of the same storage: the plan is taken
+    took = step._plan is None
+    step.plan(views[2], 2 * K)
+    raised = False
+    try:
+        step(views[0], w, neg_of(), "head-batch")                          # not the batch that was planned
+    except RuntimeError:
+        raised = True
+    step.plan(views[2], 2 * K)
+    step.drop_plan()
+    step(views[0], w, neg_of(), "head-batch")                              # plans inline (every rank alike)
+    return bool(planned and took and raised and len(calls) == 3)
+
+
+def test_row_sharded_routes_planned_ahead_are_keyed_alike_on_every_rank():
+    assert all(_run(_plan_case, world=2))

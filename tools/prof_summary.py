@@ -33,6 +33,8 @@ def timeline(path, step_kernel="adam_rows_catchup_kernel", which=-3):
     con = sqlite3.connect(path)
     rows = con.execute("select name, start, end from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if step_kernel in r[0]]
+    if len(marks) < 4:  # small tables step densely: the step then opens with the sampler's draw
+        marks = [i for i, r in enumerate(rows) if "pool_draw_kernel" in r[0]]
     lo, hi = marks[which], marks[which + 1]
     t0, prev_end, busy = rows[lo][1], rows[lo][1], 0
     print(f"{'kernel':70s} {'start_us':>9s} {'dur_us':>8s} {'gap_us':>7s}")
