@@ -182,8 +182,45 @@ def aligned_bytes(n, device):
     return raw[off: off + n]
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_exchange = getattr(torch._C, "_cuda_exchangeDevice", None)
+
+
 def stream_ptr(device=None):
+    """torch's current stream on ``device`` (default: the current device) as the ``hipStream_t`` the C ABI takes.  Through
+    torch's raw-stream query when it is there: ``torch.cuda.current_stream()`` builds a Stream object per call (~4 us -- a
+    step makes four to six library calls, and small configurations are bound by exactly this host time)."""
+    if _raw_stream is not None:
+        idx = device.index if device is not None and getattr(device, "index", None) is not None else torch.cuda.current_device()
+        return c_void_p(_raw_stream(idx))
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class on_device:
+    """``with on_device(tensor.device):`` -- ``torch.cuda.device`` without its per-call argument parsing (the library calls
+    sit inside one each: launches go to the device of their operands)."""
+
+    __slots__ = ("idx", "prev", "ctx")
+
+    def __init__(self, device):
+        self.idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+        self.prev, self.ctx = -1, None
+
+    def __enter__(self):
+        if _exchange is not None:
+            self.prev = _exchange(self.idx)
+        else:
+            self.ctx = torch.cuda.device(self.idx)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if _exchange is not None:
+            if self.prev >= 0 and self.prev != self.idx:
+                _exchange(self.prev)
+        else:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def contiguous(t, dtype):

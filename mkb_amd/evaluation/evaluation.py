@@ -71,7 +71,7 @@ class Evaluation:
         out = torch.empty(len(triples), dtype=torch.int64, device=dev)
         lib, tb = _hip.lib(), model._tables()
         ws = None
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             for lo in range(0, len(triples), chunk):
                 s = triples[lo: lo + chunk].contiguous()
                 need = lib.mkb_rank_workspace_bytes(tb, s.shape[0])

@@ -44,7 +44,7 @@ class _PoolScoreFn(torch.autograd.Function):
         B, K = sample.shape[0], info.size
         S = torch.empty((B, 2 * K), dtype=torch.float32, device=ent.device)
         ws = _workspace(model, B, K)
-        with torch.cuda.device(ent.device):
+        with _hip.on_device(ent.device):
             _hip.check(_hip.lib().mkb_pool_score_fwd(model._tables(ent, rel, modulus), _hip.ptr(sample), _hip.ptr(info.pool),
                                                      _hip.ptr(info.cnt), B, K, mode, _hip.ptr(S), _hip.ptr(ws),
                                                      _hip.stream_ptr()), "mkb_pool_score_fwd")
@@ -63,7 +63,7 @@ class _PoolScoreFn(torch.autograd.Function):
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
         ws = _workspace(model, B, K)
-        with torch.cuda.device(ent.device):
+        with _hip.on_device(ent.device):
             _hip.check(_hip.lib().mkb_pool_score_bwd(model._tables(ent, rel, modulus), gr, _hip.ptr(sample),
                                                      _hip.ptr(info.pool), _hip.ptr(info.cnt), B, K, ctx.mode, _hip.ptr(G),
                                                      _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_score_bwd")
@@ -145,7 +145,7 @@ class FusedTrainStep:
                     and st["g"].data_ptr() == ent.grad.data_ptr()):
                 gr.rows_clear = 1
             _links.mark_touched(ent, ids)  # accumulates when several steps share one optimizer.step()
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(sample), _hip.ptr(weight), _hip.ptr(info.pool),
                                                 _hip.ptr(info.cnt), B, K, mode_id, self.alpha, _hip.ptr(weight_sum),
                                                 _hip.ptr(pos), _hip.ptr(S),

@@ -21,7 +21,7 @@ class _AdversarialFn(torch.autograd.Function):
         dpos = torch.empty(B, dtype=torch.float32, device=dev)
         dneg = torch.empty((B, K), dtype=torch.float32, device=dev)
         scratch = torch.empty(B + 1, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_adversarial(_hip.ptr(pos), _hip.ptr(neg), _hip.ptr(weight), None, B, K, alpha,
                                                   None, _hip.ptr(loss), _hip.ptr(dpos), _hip.ptr(dneg), _hip.ptr(scratch),
                                                   _hip.stream_ptr()), "mkb_adversarial")

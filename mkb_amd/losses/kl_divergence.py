@@ -21,7 +21,7 @@ class _KlFn(torch.autograd.Function):
         ds = torch.empty((n, m), dtype=torch.float32, device=dev)
         dt = torch.empty((n, m), dtype=torch.float32, device=dev) if teacher.requires_grad else None
         scratch = torch.empty(n, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_kl_divergence(_hip.ptr(student), _hip.ptr(teacher), n, m, T, _hip.ptr(loss), _hip.ptr(ds),
                                                     _hip.ptr(dt), _hip.ptr(scratch), _hip.stream_ptr()), "mkb_kl_divergence")
         ctx.save_for_backward(ds, dt)

@@ -44,7 +44,7 @@ class _ScoreFn(torch.autograd.Function):
         K = 1 if cand is None else cand.shape[1]
         score = torch.empty((B, K), dtype=torch.float32, device=ent.device)
         tb = model._tables(ent, rel, modulus)
-        with torch.cuda.device(ent.device):
+        with _hip.on_device(ent.device):
             _hip.check(_hip.lib().mkb_score_fwd(tb, _hip.ptr(sample), _hip.ptr(cand), B, K, mode, _hip.ptr(score),
                                                 _hip.stream_ptr()), "mkb_score_fwd")
         ctx.model, ctx.mode = model, mode
@@ -62,7 +62,7 @@ class _ScoreFn(torch.autograd.Function):
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         tb = model._tables(ent, rel, modulus)
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
-        with torch.cuda.device(ent.device):
+        with _hip.on_device(ent.device):
             n_ws = _hip.lib().mkb_score_bwd_workspace_bytes(tb, B, K, ctx.mode)  # the glue owns every buffer (mkb_hip.h)
             ws = _hip.aligned_bytes(n_ws, ent.device) if n_ws > 0 else None
             _hip.check(_hip.lib().mkb_score_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(cand), B, K, ctx.mode,
@@ -223,7 +223,7 @@ class BaseModel(Base):
         cand = None
         if negative_sample is not None and getattr(negative_sample, "_mkb_pool", None) is None:  # (our sampler's output is trusted)
             cand = _hip.contiguous(negative_sample, torch.int64)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_check_ids(_hip.ptr(sample), sample.shape[0], _hip.ptr(cand), 0 if cand is None else cand.numel(),
                                                 self.n_entity, self.n_relation, _hip.ptr(flag), _hip.stream_ptr()), "mkb_check_ids")
 

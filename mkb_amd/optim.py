@@ -87,7 +87,7 @@ class Adam:
         ids = _hip.contiguous(ids, torch.int64)
         st["caught_up"] = (ids, upto)
         lib, c = _hip.lib(), self._consts(st, upto)
-        with torch.cuda.device(p.device):
+        with _hip.on_device(p.device):
             if st.get("defer"):
                 _hip.check(lib.mkb_adam_rows_advance(_hip.ptr(p.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
                                                      _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1], _hip.ptr(ids),
@@ -113,7 +113,7 @@ class Adam:
         lib, c = _hip.lib(), self._consts(st, upto)
         defer = bool(st.get("defer"))
         n_loc = 0 if local_ids is None else local_ids.numel()
-        with torch.cuda.device(p.device):
+        with _hip.on_device(p.device):
             _hip.check(lib.mkb_adam_rows_advance_sharded(
                 _hip.ptr(p.data), _hip.ptr(st["g"]) if defer else None, _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
                 _hip.ptr(c), p.shape[0], p.shape[1], _hip.ptr(global_ids), global_ids.numel(), world, rank,
@@ -130,7 +130,7 @@ class Adam:
         lib, c = _hip.lib(), self._consts(st, max(upto, 1))
         defer = bool(st.get("defer"))
         n_loc = 0 if local_ids is None else local_ids.numel()
-        with torch.cuda.device(p.device):
+        with _hip.on_device(p.device):
             _hip.check(lib.mkb_adam_rows_advance_sharded_generate(
                 _hip.ptr(p.data), _hip.ptr(st["g"]) if defer else None, _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]),
                 _hip.ptr(c), p.shape[0], p.shape[1], world, rank, _hip.ptr(local_ids) if n_loc else None, n_loc, upto,
@@ -146,7 +146,7 @@ class Adam:
         lib, c = _hip.lib(), self._consts(st, max(upto, 1))
         tail = (sampler_handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg), _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt),
                 _hip.ptr(touched), _hip.stream_ptr())
-        with torch.cuda.device(p.device):
+        with _hip.on_device(p.device):
             if st.get("defer"):
                 _hip.check(lib.mkb_adam_rows_advance_generate(
                     _hip.ptr(p.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]), _hip.ptr(st["v"]), _hip.ptr(st["last"]), _hip.ptr(c),
@@ -168,7 +168,7 @@ class Adam:
             if st["n"] <= 0 or st.get("flushed") == st["n"]:
                 continue
             c = self._consts(st, st["n"])
-            with torch.cuda.device(q.device):
+            with _hip.on_device(q.device):
                 if st.get("defer"):
                     _hip.check(lib.mkb_adam_rows_advance(_hip.ptr(q.data), _hip.ptr(st["g"]), _hip.ptr(st["m"]),
                                                          _hip.ptr(st["v"]), _hip.ptr(st["last"]), _hip.ptr(c), q.shape[0],
@@ -184,7 +184,7 @@ class Adam:
         pend, self._pending_dense = self._pending_dense, None
         if pend is not None:  # no launch above carried it (its table was already flushed): step it on its own
             q, d, lr, _ = pend
-            with torch.cuda.device(q.device):
+            with _hip.on_device(q.device):
                 _hip.check(lib.mkb_adam_step(d.param, d.grad, d.exp_avg, d.exp_avg_sq, d.n, d.step, lr, self.betas[0],
                                              self.betas[1], self.eps, 1, _hip.stream_ptr()), "mkb_adam_step")
 
@@ -235,7 +235,7 @@ class Adam:
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
             touched = _links.take_touched(p) if _links.owner(p) is self else None
-            with torch.cuda.device(p.device):
+            with _hip.on_device(p.device):
                 if touched is not None:
                     done = st.get("caught_up")
                     caught = done is not None and done[1] == st["n"]  # a catch-up at this step count preceded the gradient

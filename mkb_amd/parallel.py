@@ -269,7 +269,7 @@ class DimShardedStep:
         bounds = [(B * i // nmb, B * (i + 1) // nmb) for i in range(nmb)]
         wsum = weight.sum().reshape(1) if nmb > 1 else None          # W of the WHOLE batch (every rank has all rows)
         parts, works = [], []
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             for lo, hi in bounds:                                     # forward halves + their all-reduces (async)
                 b = hi - lo
                 scores = torch.empty(b * (2 * K + 1), dtype=torch.float32, device=dev)  # [pos | pool]: one collective

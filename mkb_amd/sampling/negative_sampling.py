@@ -129,7 +129,7 @@ class NegativeSampling:
         tk, to, tv, _ = self._tail_csr
         handle = ctypes.c_void_p()
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        with torch.cuda.device(device):
+        with _hip.on_device(device):
             _hip.check(_hip.lib().mkb_sampler_create(ctypes.byref(handle), self.n_entity, self.n_relation, self.size,
                                                      int(self.seed) & 0xFFFFFFFF, p(hk), len(hk), p(ho), p(hv), p(tk),
                                                      len(tk), p(to), p(tv), _hip.stream_ptr()), "mkb_sampler_create")
@@ -152,7 +152,7 @@ class NegativeSampling:
         cnt = torch.empty((B, 2 * K), dtype=torch.uint16, device=dev)
         touched = torch.empty(2 * K + 2 * B, dtype=torch.int64, device=dev)  # pool | heads | tails (row-lazy Adam)
         mode_id = _hip.mode_id(mode)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_sampler_generate(self._handle, _hip.ptr(sample), B, mode_id, _hip.ptr(neg),
                                                        _hip.ptr(pool), _hip.ptr(pos), _hip.ptr(cnt), _hip.ptr(touched),
                                                        _hip.stream_ptr()), "mkb_sampler_generate")
@@ -211,7 +211,7 @@ class NegativeSampling:
         """Raise what the reference would have raised for the batches generated so far (synchronises)."""
         if self._handle is None:
             return
-        with torch.cuda.device(self._device):
+        with _hip.on_device(self._device):
             rc = _hip.lib().mkb_sampler_status(self._handle, _hip.stream_ptr())
         if rc == 0:
             return
@@ -227,7 +227,7 @@ class NegativeSampling:
             return st[1].astype(np.uint32), int(st[2])
         key = np.empty(624, dtype=np.uint32)
         pos = ctypes.c_int32()
-        with torch.cuda.device(self._device):
+        with _hip.on_device(self._device):
             _hip.check(_hip.lib().mkb_sampler_get_state(self._handle, key.ctypes.data_as(ctypes.c_void_p),
                                                         ctypes.byref(pos), _hip.stream_ptr()), "mkb_sampler_get_state")
         return key, pos.value
@@ -236,7 +236,7 @@ class NegativeSampling:
         key = np.ascontiguousarray(key, dtype=np.uint32)
         if self._handle is None:
             self._ensure_handle(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
-        with torch.cuda.device(self._device):
+        with _hip.on_device(self._device):
             _hip.check(_hip.lib().mkb_sampler_set_state(self._handle, key.ctypes.data_as(ctypes.c_void_p), int(pos),
                                                         _hip.stream_ptr()), "mkb_sampler_set_state")
 

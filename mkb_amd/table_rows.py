@@ -99,7 +99,7 @@ class HipRowOps:
         slot = torch.empty(m, dtype=torch.int32, device=dev)
         counts = torch.empty(world, dtype=torch.int64, device=dev)
         compact = torch.empty((n, 3), dtype=torch.int64, device=dev) if sample_layout else None
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_rows_route(_hip.ptr(ids), n, 1 if sample_layout else 0, world, row0, _hip.ptr(send),
                                                  _hip.ptr(slot), _hip.ptr(counts), _hip.ptr(compact), _hip.ptr(self._flag(dev)),
                                                  _hip.stream_ptr()),
@@ -110,7 +110,7 @@ class HipRowOps:
         """``occ`` ([shard rows] int32, zeroed once): count how often each shard row is listed, for the matching
         ``scatter_add`` of the same segments (which resets the counts)."""
         _hip.require_device(shard)
-        with torch.cuda.device(shard.device):
+        with _hip.on_device(shard.device):
             _hip.check(_hip.lib().mkb_rows_gather(
                 _hip.ptr(shard), shard.shape[0], shard.shape[1], self._segs(segs), len(segs), _hip.ptr(weight),
                 0 if weight is None else weight.numel(), _hip.ptr(weight_sum), _hip.ptr(zero),
@@ -120,7 +120,7 @@ class HipRowOps:
 
     def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
         _hip.require_device(grad)
-        with torch.cuda.device(grad.device):
+        with _hip.on_device(grad.device):
             _hip.check(_hip.lib().mkb_rows_scatter_add(
                 _hip.ptr(grad), grad.shape[0], grad.shape[1], self._segs(segs), len(segs), _hip.ptr(dense_dst),
                 _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(occ), _hip.ptr(self._flag(grad.device)),
@@ -241,7 +241,15 @@ class _Route:
             return
         tb = self.table
         if self._ready is not None:  # the route was made on the side stream: the step's stream takes over from here
-            torch.cuda.current_stream(self.send_ids.device).wait_event(self._ready)
+            main = torch.cuda.current_stream(self.send_ids.device)
+            main.wait_event(self._ready)
+            # ... and the route's buffers, which the allocator handed out on the SIDE stream, are now read by the step's
+            # kernels: without this the next plan() -- issued on the side stream while those kernels may still be in flight --
+            # could be given the same memory the moment this route is dropped (seen as a rare wrong loss under RCCL)
+            for t in (self.send_ids, self.slot, self.counts, self.compact):
+                if t is not None:
+                    t.record_stream(main)
+            self._ready = None
         if not _collectives_run(tb.world):
             self.sc, self.rc = [self.n], [self.n]
             self.listed = torch.empty(lead + self.n, dtype=torch.int64, device=self.send_ids.device)
@@ -429,7 +437,7 @@ class TableRowShardedStep:
         ws = _workspace(m, b, K)
         # (the compact gradient was cleared by this step's gather launch: every row the step writes starts from zero)
         gr = _hip.Grads(bufs["grad"].data_ptr(), bufs["g_rel"].data_ptr(), bufs["g_mod"].data_ptr() if self._trains_modulus else None, 1)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().mkb_pool_step(m._tables(), gr, _hip.ptr(compact), _hip.ptr(weight), _hip.ptr(bufs["pool_ids"]),
                                                 _hip.ptr(info.cnt), b, K, _hip.mode_id(mode), self.alpha, _hip.ptr(bufs["wsum"]),
                                                 _hip.ptr(pos), _hip.ptr(S), _hip.ptr(bufs["loss"]), _hip.ptr(ws),

