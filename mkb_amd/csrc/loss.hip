@@ -80,8 +80,12 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     float *s_v = s_dyn;                                  // TILE: [cap][9] (also the seed tile that goes out), else [K][5]
     float *s_e = s_dyn + (size_t)(TILE ? cap : K) * RS;  // [K][RS] (staged rows only)
     if constexpr (TILE) {
-        for (int e = threadIdx.x; e < cap * RS; e += NTH) s_v[e] = 0.f;  // (padding slots and rows past the batch stay 0)
-        __syncthreads();
+        // padding positions [K, cap) and rows past the batch must read as 0 in the tile that goes out; a full tile of a
+        // pool that fills its layout (the headline shape) has neither: no clearing pass, no barrier (workgroup-uniform)
+        if (K < cap || (int)(blockIdx.x + 1) * RPB > B) {
+            for (int e = threadIdx.x; e < cap * RS; e += NTH) s_v[e] = 0.f;
+            __syncthreads();
+        }
     }
     if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
         const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6);
