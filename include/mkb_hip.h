@@ -126,6 +126,11 @@ int mkb_sampler_create(mkb_sampler_t **out, int64_t n_entity, int64_t n_relation
 int mkb_sampler_generate(mkb_sampler_t *s, const int64_t *sample, int64_t B, int mode, int64_t *neg,
                          int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream);
 int mkb_sampler_status(mkb_sampler_t *s, void *stream); /* synchronises `stream`; returns 0 or the error */
+/* Optional NON-PARITY pool draw (the reference has no counterpart; BASELINE north_star names it): kind 1 = rocRAND
+ * Philox4x32-10 inside the same draw kernel (masked rejection like numpy's randint; counter based, so `draws` -- the number
+ * of pools drawn so far -- is the whole generator state); kind 0 (default) = numpy's legacy MT19937, bit-exact negatives. */
+int mkb_sampler_set_rng(mkb_sampler_t *s, int kind, uint64_t seed, uint64_t draws);
+int mkb_sampler_get_rng(mkb_sampler_t *s, int *kind, uint64_t *seed, uint64_t *draws);
 int mkb_sampler_get_state(mkb_sampler_t *s, uint32_t *key624_host, int32_t *pos_host, void *stream);
 int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_host, int32_t pos, void *stream);
 void mkb_sampler_destroy(mkb_sampler_t *s);

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "mkb_sampler_generate": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
     "mkb_sampler_status": (c_int, [c_void_p, c_void_p]),
+    "mkb_sampler_set_rng": (c_int, [c_void_p, c_int, ctypes.c_uint64, ctypes.c_uint64]),
+    "mkb_sampler_get_rng": (c_int, [c_void_p, POINTER(c_int), POINTER(ctypes.c_uint64), POINTER(ctypes.c_uint64)]),
     "mkb_sampler_get_state": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
     "mkb_sampler_set_state": (c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     "mkb_sampler_destroy": (None, [c_void_p]),

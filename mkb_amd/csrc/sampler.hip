@@ -39,13 +39,17 @@ struct mkb_sampler {
     uint32_t *mt_prev; // device [625]: generator state before a pool drawn ahead (sampler_draw_ahead)
     int cur;
     bool drawn_ahead;  // the next generate's pool is already in buffer cur ^ 1
+    int rng_kind = 0;                              // 0: numpy MT19937 (bit-exact with the reference); 1: rocRAND Philox4x32-10
+    unsigned long long fast_seed = 0, fast_draw = 0;  // rocRAND mode: seed and the number of pools drawn so far
     mkb::Csr head, tail;
     int P() const { return (int)(2 * K); }
     int P2() const { int p2 = 2; while (p2 < P()) p2 <<= 1; return p2; }
     mkb::DrawArgs draw_args(int buf, int64_t *pool_out, bool save_prev) {
-        return mkb::DrawArgs{mt, mtpos, save_prev ? mt_prev : nullptr, (uint32_t)(n_entity - 1), P(), P2(),
-                             pool + (size_t)buf * P(), pool_out, lastflag + (size_t)buf * P(),
-                             sorted_val + (size_t)buf * P2(), sorted_pos + (size_t)buf * P2()};
+        mkb::DrawArgs D{mt, mtpos, save_prev ? mt_prev : nullptr, (uint32_t)(n_entity - 1), P(), P2(),
+                        pool + (size_t)buf * P(), pool_out, lastflag + (size_t)buf * P(),
+                        sorted_val + (size_t)buf * P2(), sorted_pos + (size_t)buf * P2(), rng_kind, fast_seed, fast_draw};
+        if (rng_kind == 1) ++fast_draw;  // (every DrawArgs built is one pool drawn: the launch is enqueued by the caller)
+        return D;
     }
 };
 
@@ -167,6 +171,23 @@ extern "C" int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_ho
     MKB_CHECK_HIP(hipMemcpyAsync(s->mtpos, &pos, sizeof(int32_t), hipMemcpyHostToDevice, st));
     MKB_CHECK_HIP(hipMemcpyAsync(s->status, zero, sizeof(zero), hipMemcpyHostToDevice, st));
     MKB_CHECK_HIP(hipStreamSynchronize(st));
+    return MKB_OK;
+}
+
+// Optional non-parity draw (BASELINE north_star: "a rocRAND + HIP reject kernel"): kind 1 = rocRAND's Philox4x32-10, counter
+// based (no device state: `draws` pools have been drawn so far -- pass 0 for a fresh sampler, or the value of
+// mkb_sampler_get_rng to resume).  kind 0 (the default) = numpy's legacy MT19937 stream, bit-exact with the reference.
+extern "C" int mkb_sampler_set_rng(mkb_sampler_t *s, int kind, uint64_t seed, uint64_t draws) {
+    MKB_REQUIRE(s != nullptr && (kind == 0 || kind == 1), "bad sampler / rng kind");
+    MKB_REQUIRE(!s->drawn_ahead || kind == s->rng_kind, "a pool drawn ahead is pending: switch generators before the first generate");
+    s->rng_kind = kind; s->fast_seed = seed; s->fast_draw = draws;
+    return MKB_OK;
+}
+
+extern "C" int mkb_sampler_get_rng(mkb_sampler_t *s, int *kind, uint64_t *seed, uint64_t *draws) {
+    MKB_REQUIRE(s && kind && seed && draws, "null pointer");
+    // (a pool drawn ahead has not been handed out yet: a resumed sampler must draw it again)
+    *kind = s->rng_kind; *seed = s->fast_seed; *draws = s->fast_draw - ((s->rng_kind == 1 && s->drawn_ahead) ? 1 : 0);
     return MKB_OK;
 }
 

@@ -5,6 +5,8 @@
 #pragma once
 #include "common.h"
 
+#include <rocrand/rocrand_kernel.h>  // device-side Philox4x32-10 (header only): the optional non-parity draw
+
 namespace mkb {
 
 constexpr int MT_N = 624, MT_M = 397;
@@ -19,6 +21,11 @@ struct DrawArgs {
     int64_t *pool2;        // null, or the caller's [P] output
     uint8_t *lastflag;     // [P]
     int32_t *sorted_val, *sorted_pos;  // [P2]
+    // rng_kind 1: the pool comes from rocRAND's Philox4x32-10 instead of numpy's MT19937 stream (NOT the reference's
+    // negatives: same distribution, other numbers).  Counter based: pool entry p of draw number `fast_draw` is the first
+    // accepted output of subsequence fast_draw * P + p -- no generator state on the device, every lane draws on its own
+    int rng_kind;
+    unsigned long long fast_seed, fast_draw;
 };
 inline size_t draw_lds_bytes(int P, int P2) { return (size_t)P2 * 8 + (size_t)P * 4; }
 
@@ -78,6 +85,18 @@ __device__ __forceinline__ void pool_draw_body(const DrawArgs &D, unsigned long 
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     __syncthreads();
     int have = 0;
+    if (D.rng_kind == 1 && rng != 0) {  // rocRAND: uniform on [0, rng] by masked rejection, like numpy's randint
+        for (int p2 = tid; p2 < P; p2 += NT) {
+            rocrand_state_philox4x32_10 st;
+            rocrand_init(D.fast_seed, D.fast_draw * (unsigned long long)P + (unsigned long long)p2, 0ull, &st);
+            uint32_t v;
+            do { v = rocrand(&st) & mask; } while (v > rng);
+            pool[p2] = (int64_t)v;
+            if (pool2) pool2[p2] = (int64_t)v;
+            pool_out_l[p2] = v;
+        }
+        have = P;
+    }
     if (rng == 0) {  // randint(1): no stream consumption
         for (int p = tid; p < P; p += NT) { pool[p] = 0; if (pool2) pool2[p] = 0; pool_out_l[p] = 0; }
         have = P;

@@ -98,7 +98,14 @@ class PoolInfo:
 
 
 class NegativeSampling:
-    def __init__(self, size, train_triples, entities, relations, seed=42):
+    def __init__(self, size, train_triples, entities, relations, seed=42, rng="numpy"):
+        """``rng="numpy"`` (default): the reference's ``np.random.RandomState(seed).randint`` stream, bit-exact negatives.
+        ``rng="rocrand"``: opt-in, NOT the reference's numbers -- the pool comes from rocRAND's Philox4x32-10 inside the same
+        draw kernel (counter based: no generator state on the device, every lane draws its own entry; the filter, the
+        cyclic fill and every other semantic are unchanged)."""
+        if rng not in ("numpy", "rocrand"):
+            raise ValueError("rng must be 'numpy' (bit-exact with the reference) or 'rocrand'")
+        self.rng = rng
         self.size = size
         self.n_entity = len(entities)
         self.n_relation = len(relations)
@@ -134,6 +141,8 @@ class NegativeSampling:
                                                      int(self.seed) & 0xFFFFFFFF, p(hk), len(hk), p(ho), p(hv), p(tk),
                                                      len(tk), p(to), p(tv), _hip.stream_ptr()), "mkb_sampler_create")
         self._handle, self._device = handle, device
+        if self.rng == "rocrand":
+            _hip.check(_hip.lib().mkb_sampler_set_rng(handle, 1, int(self.seed) & 0xFFFFFFFFFFFFFFFF, 0), "mkb_sampler_set_rng")
 
     def generate(self, sample, mode):
         """-> LongTensor [B, size] on ``sample``'s device (reference: CPU tensor; ``.to(device)`` is then free)."""
@@ -222,6 +231,13 @@ class NegativeSampling:
 
     # ---- RNG state (numpy MT19937 key + position), e.g. for checkpoint/resume or multi-GPU replication
     def get_state(self):
+        if self.rng == "rocrand":  # counter based: (seed, pools drawn so far) is the whole state
+            if self._handle is None:
+                return "rocrand", (int(self.seed), 0)
+            kind, seed, draws = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_uint64()
+            _hip.check(_hip.lib().mkb_sampler_get_rng(self._handle, ctypes.byref(kind), ctypes.byref(seed), ctypes.byref(draws)),
+                       "mkb_sampler_get_rng")
+            return "rocrand", (int(seed.value), int(draws.value))
         if self._handle is None:
             st = np.random.RandomState(self.seed).get_state()
             return st[1].astype(np.uint32), int(st[2])
@@ -233,6 +249,13 @@ class NegativeSampling:
         return key, pos.value
 
     def set_state(self, key, pos, device=None):
+        if isinstance(key, str):  # ("rocrand", (seed, draws)) from get_state()
+            if key != "rocrand" or self.rng != "rocrand":
+                raise ValueError("generator state of another kind than this sampler's")
+            if self._handle is None:
+                self._ensure_handle(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+            _hip.check(_hip.lib().mkb_sampler_set_rng(self._handle, 1, int(pos[0]) & 0xFFFFFFFFFFFFFFFF, int(pos[1])), "mkb_sampler_set_rng")
+            return
         key = np.ascontiguousarray(key, dtype=np.uint32)
         if self._handle is None:
             self._ensure_handle(torch.device("cuda", torch.cuda.current_device()) if device is None else device)

@@ -187,3 +187,44 @@ def test_sampler_riding_the_catch_up_launch_is_bit_identical(size):
     assert torch.equal(tables[0][1], tables[1][1])
     (ka, pa), (kb, pb) = tables[0][2], tables[1][2]
     assert pa == pb and np.array_equal(ka, kb)  # the riding sampler holds a pool drawn ahead: same logical state
+
+
+def test_rocrand_pool_draw_is_uniform_filtered_and_resumable():
+    """rng="rocrand" (opt-in, NOT the reference's numbers): the pool comes from rocRAND's Philox4x32-10 inside the draw
+    kernel; everything else is the reference's algorithm.  Checked: ids in range, one shared pool per batch (<= 2K distinct
+    negatives), every row's negatives avoid its true set and follow the first-K-survivors-cyclically rule against THAT
+    pool, the draw is roughly uniform, differs from the numpy stream, is reproducible at a seed, and resumes exactly."""
+    from mkb_amd import datasets, sampling
+
+    ds = datasets.Fb15k237(batch_size=256, shuffle=False, seed=42, num_workers=0)
+    train = np.asarray(ds.train, dtype=np.int64)
+    K, B = 64, 256
+    s = torch.as_tensor(train[np.random.RandomState(1).randint(len(train), size=B)]).cuda()
+
+    def make(rng, seed=7):
+        return sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=seed, rng=rng)
+
+    a, b, ref = make("rocrand"), make("rocrand"), make("numpy")
+    outs = []
+    for mode in ("head-batch", "tail-batch", "head-batch"):
+        na, nb, nr = a.generate(s, mode), b.generate(s, mode), ref.generate(s, mode)
+        a.check()
+        assert torch.equal(na, nb) and not torch.equal(na, nr)
+        info = na._mkb_pool
+        pool = info.pool.cpu().numpy()
+        assert pool.min() >= 0 and pool.max() < len(ds.entities) and len(np.unique(na.cpu().numpy())) <= 2 * K
+        true = a.true_head if mode == "head-batch" else a.true_tail
+        neg = na.cpu().numpy()
+        for i in range(0, B, 17):  # the reference's rule against this pool: survivors of the filter, cyclically, first K
+            h, r, t = (int(v) for v in s[i].cpu())
+            rec = true[(r, t)] if mode == "head-batch" else true[(h, r)]
+            keep = pool[np.isin(pool, rec, assume_unique=True, invert=True)]
+            want = np.concatenate([keep] * (K // max(1, len(keep)) + 1))[:K]
+            np.testing.assert_array_equal(neg[i], want)
+        outs.append(pool)
+    allp = np.concatenate(outs)
+    assert abs(allp.mean() / (len(ds.entities) - 1) - 0.5) < 0.08 and len(np.unique(allp)) > 0.9 * len(allp) * (1 - len(allp) / len(ds.entities))
+    # resume: a fresh sampler set to a's state continues with a's next pool
+    c = make("rocrand", seed=1)
+    c.set_state(*a.get_state())
+    assert torch.equal(a.generate(s, "tail-batch"), c.generate(s, "tail-batch"))
