@@ -1,0 +1,7 @@
+# A/B of library variants on the kernel class given as $1: bash tools/_kb2.sh pool_bwd_q dyn stat
+cls=$1; shift
+for rep in 1 2; do for v in "$@"; do
+  for c in headline wn18rr-rotate yago310-rotate; do
+    echo -n "$v $c: "; MKB_HIP_LIB=$PWD/variants/lib_$v.so python bench.py --config $c --no-traffic --no-cpu-baseline --mrr-epochs 0 --no-variants --profile-kernel $cls --steps 300 --warmup 30 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['ms_per_step'],4), round(j['roofline']['avg_kernel_us'],1) if j.get('roofline') else None)"
+  done
+done; done
