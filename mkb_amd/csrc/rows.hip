@@ -11,6 +11,8 @@
 // round trip (the split sizes of the all-to-alls are read back one batch AHEAD, see table_rows.py).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace mkb {
 
 constexpr int kRouteThreads = 1024;
@@ -27,14 +29,52 @@ struct RouteArgs {
     int64_t *counts;        // [world]
     int64_t *compact;       // [b, 3] the triples re-addressed into the compact table: (row0 + slot[j], r, row0 + slot[b + j])
     int *bad;               // raised for a negative id (the reference raises IndexError, models/base.py:193-207); it is routed as id 0
+    int merge_cap;          // slots of the LDS merge table (power of two >= 2 x requests), 0 = requests are not merged
 };
 
-// One workgroup: a counting sort by owner done as `world` stable compactions (a few block scans of 1024 flags each; the
-// list is 2b <= a few thousand ids, so this is latency, not bandwidth).
+// One workgroup.  Requests for the SAME row are merged first: a batch's heads and tails repeat (a hub entity is the head of
+// dozens of a batch's triples; the synthetic YAGO3-10 of config 5 draws them Zipf-distributed), and every repeat used to be
+// its own row of the compact table -- gathered, sent through the all-to-all, and its gradient row sent back and added with
+// atomics at the owner.  Now request j takes the slot of the FIRST request for its row (an open-addressing table in LDS finds
+// it: key = row id, value = smallest request index), the compact triples of the repeats point at that one row (the fused
+// step's own occurrence counts then make its writers use atomics, exactly as on one GPU), and the lists that travel hold
+// every row once.  Then a counting sort of the first requests by owner, done as `world` stable compactions (a few block
+// scans of 1024 flags each; the list is 2b <= a few thousand ids, so this is latency, not bandwidth).  send_ids beyond the
+// merged count are -1 (the row kernels skip such entries).
 __global__ __launch_bounds__(kRouteThreads) void rows_route_kernel(RouteArgs A) {
+    extern __shared__ __attribute__((aligned(8))) unsigned long long s_route[];  // merge table: [cap] keys, then [cap] ints
     __shared__ int s_cnt[kRouteThreads / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = A.flat ? A.n_flat : 2 * A.b;
+    const int cap = A.merge_cap;  // power of two >= 2 n, or 0: no merging (lists too long for the LDS table)
+    unsigned long long *s_key = s_route;
+    int *s_first = reinterpret_cast<int *>(s_route + cap);
+    auto id_of = [&](int j) -> int64_t {
+        int64_t id = A.flat ? A.sample[j] : (j < A.b ? A.sample[3 * (int64_t)j] : A.sample[3 * (int64_t)(j - A.b) + 2]);
+        if (id < 0) {  // (no owner: the request still gets a slot -- row 0's --, the caller is told)
+            if (A.bad) atomicOr(A.bad, 1);
+            id = 0;
+        }
+        return id;
+    };
+    auto home = [&](int64_t id) { return (int)((((unsigned long long)id * 0x9E3779B97F4A7C15ull) >> 40) & (unsigned long long)(cap - 1)); };
+    if (cap) {
+        for (int e = tid; e < cap; e += kRouteThreads) { s_key[e] = ~0ull; s_first[e] = 0x7fffffff; }
+        __syncthreads();
+        for (int j = tid; j < n; j += kRouteThreads) {
+            const unsigned long long id = (unsigned long long)id_of(j);
+            for (int h = home((int64_t)id);; h = (h + 1) & (cap - 1)) {
+                const unsigned long long prev = atomicCAS(&s_key[h], ~0ull, id);
+                if (prev == ~0ull || prev == id) { atomicMin(&s_first[h], j); break; }
+            }
+        }
+        __syncthreads();
+    }
+    auto first_of = [&](int j, int64_t id) {
+        if (!cap) return j;
+        for (int h = home(id);; h = (h + 1) & (cap - 1))
+            if (s_key[h] == (unsigned long long)id) return s_first[h];
+    };
     int offset = 0;
     for (int w = 0; w < A.world; ++w) {
         const int start = offset;
@@ -43,12 +83,8 @@ __global__ __launch_bounds__(kRouteThreads) void rows_route_kernel(RouteArgs A) 
             int64_t id = 0;
             bool flag = false;
             if (j < n) {
-                id = A.flat ? A.sample[j] : (j < A.b ? A.sample[3 * (int64_t)j] : A.sample[3 * (int64_t)(j - A.b) + 2]);
-                if (id < 0) {  // (no owner: every request still gets a slot, the caller is told)
-                    if (w == 0 && A.bad) atomicOr(A.bad, 1);
-                    id = 0;
-                }
-                flag = (int)(id % A.world) == w;
+                id = id_of(j);
+                flag = (int)(id % A.world) == w && first_of(j, id) == j;
             }
             const unsigned long long bal = __ballot(flag);
             if (lane == 0) s_cnt[wave] = __popcll(bal);
@@ -61,16 +97,26 @@ __global__ __launch_bounds__(kRouteThreads) void rows_route_kernel(RouteArgs A) 
                 total += c;
             }
             if (flag) {
-                const int s = offset + before + __popcll(bal & ((1ull << lane) - 1ull));
-                A.send_ids[s] = id / A.world;
-                A.slot[j] = s;
+                const int sl = offset + before + __popcll(bal & ((1ull << lane) - 1ull));
+                A.send_ids[sl] = id / A.world;
+                A.slot[j] = sl;
             }
             offset += total;
             __syncthreads();
         }
         if (tid == 0) A.counts[w] = offset - start;
     }
-    __syncthreads();  // slot[] was written by other lanes of this workgroup
+    __threadfence_block();
+    __syncthreads();  // the first requests' slots were written by other lanes of this workgroup
+    for (int j = tid; j < n; j += kRouteThreads) {
+        if (j >= offset) A.send_ids[j] = -1;  // (positions behind the merged list)
+        if (cap) {
+            const int f = first_of(j, id_of(j));
+            if (f != j) A.slot[j] = A.slot[f];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     if (A.compact && !A.flat) {
         for (int j = tid; j < A.b; j += kRouteThreads) {
             A.compact[3 * (int64_t)j] = A.row0 + A.slot[j];
@@ -246,8 +292,19 @@ extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, 
     MKB_REQUIRE(ids && send_ids && slot && counts, "null pointer");
     MKB_REQUIRE(n > 0 && 2 * n <= INT32_MAX && world >= 1 && world <= 4096, "bad n / world");
     MKB_REQUIRE(sample_layout || !compact, "the compact triples need the [b, 3] layout");
-    RouteArgs A{ids, sample_layout ? (int)n : 0, world, sample_layout ? 0 : 1, (int)n, row0, send_ids, slot, counts, compact, bad};
-    hipLaunchKernelGGL(rows_route_kernel, dim3(1), dim3(kRouteThreads), 0, (hipStream_t)stream, A);
+    RouteArgs A{ids, sample_layout ? (int)n : 0, world, sample_layout ? 0 : 1, (int)n, row0, send_ids, slot, counts, compact, bad, 0};
+    const int64_t reqs = sample_layout ? 2 * n : n;
+    int cap = 2;
+    while (cap < 2 * reqs && cap <= 8192) cap <<= 1;
+    static const bool no_merge = getenv("MKB_ROWS_NO_MERGE") != nullptr;  // A/B switch
+    size_t lds = 0;
+    if (cap <= 8192 && !no_merge) {  // 12 bytes per slot: 96 KB at the limit (4096 requests = 2048 triples per rank and step)
+        A.merge_cap = cap;
+        lds = (size_t)cap * 12;
+        static LdsOptIn grant;
+        if (int rc = grant.ensure(reinterpret_cast<const void *>(&rows_route_kernel), lds)) return rc;
+    }
+    hipLaunchKernelGGL(rows_route_kernel, dim3(1), dim3(kRouteThreads), lds, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }

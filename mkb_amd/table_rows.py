@@ -7,7 +7,8 @@
 * the global batch is cut by rows (every rank scores its own triples) against ONE candidate pool -- every rank replays the
   same MT19937 stream, so the negatives are bit-identical to a single-process run;
 * per step
-    0. (one batch AHEAD) ``mkb_rows_route`` groups the rank's 2b positive-row requests by owner; the per-owner counts are
+    0. (one batch AHEAD) ``mkb_rows_route`` merges the rank's 2b positive-row requests by row (a hub entity is requested once,
+       however many of the batch's triples hold it) and groups them by owner; the per-owner counts are
        exchanged and read back on a side stream, the id lists follow -- so the all-to-alls of step t have host-known split
        sizes without the host ever waiting on the compute stream;
     1. the owners bring the rows about to be read up to date (``mkb_adam_rows_advance_sharded``) and read them
@@ -183,8 +184,8 @@ class RowShardedTable:
         return got[slot.long()], route
 
     def scatter_add_private(self, route, grad_rows):
-        grouped = torch.empty_like(grad_rows)
-        grouped[route.slot.long()] = grad_rows
+        grouped = torch.zeros_like(grad_rows)
+        grouped.index_add_(0, route.slot.long(), grad_rows)  # (requests for the same row share a slot: their gradients add)
         back = torch.empty((route.want.numel(), self.dim), dtype=grad_rows.dtype, device=grad_rows.device)
         route.rows_to_owners(grouped, back)
         self.ops.scatter_add(self._grad(), [(route.want, back, 0, 0, None)])
@@ -264,22 +265,24 @@ class _Route:
         self.sc, self.rc = host[: tb.world], host[tb.world:]
         self.listed = torch.empty(lead + sum(self.rc), dtype=torch.int64, device=self.send_ids.device)
         self.want = self.listed[lead:]
-        dist.all_to_all_single(self.want, self.send_ids, output_split_sizes=self.rc, input_split_sizes=self.sc, group=tb.group)
+        # (requests for the same row were merged by the route kernel: send_ids holds sum(sc) rows, then -1 padding)
+        dist.all_to_all_single(self.want, self.send_ids[: sum(self.sc)], output_split_sizes=self.rc, input_split_sizes=self.sc,
+                               group=tb.group)
 
     # rows [sum(rc), D] read by this owner -> the requesters' buffers [n, D] (grouped order), and the way back
     def rows_to_requesters(self, reply, got, async_op=False):
         if not _collectives_run(self.table.world):
             got.copy_(reply)
             return None
-        return dist.all_to_all_single(got, reply, output_split_sizes=self.sc, input_split_sizes=self.rc, group=self.table.group,
-                                      async_op=async_op)
+        return dist.all_to_all_single(got[: sum(self.sc)], reply, output_split_sizes=self.sc, input_split_sizes=self.rc,
+                                      group=self.table.group, async_op=async_op)
 
     def rows_to_owners(self, grouped, back, async_op=False):
         if not _collectives_run(self.table.world):
             back.copy_(grouped)
             return None
-        return dist.all_to_all_single(back, grouped, output_split_sizes=self.rc, input_split_sizes=self.sc, group=self.table.group,
-                                      async_op=async_op)
+        return dist.all_to_all_single(back, grouped[: sum(self.sc)], output_split_sizes=self.rc, input_split_sizes=self.sc,
+                                      group=self.table.group, async_op=async_op)
 
 
 def shard_table_rows(model, group=None, device=None, ops=None):

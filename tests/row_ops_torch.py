@@ -5,14 +5,26 @@ import torch
 
 
 class TorchRowOps:
-    def route(self, ids, world, row0=0, sample_layout=False):
+    def route(self, ids, world, row0=0, sample_layout=False, merge=True):
+        """Requests for the same row share the slot of the FIRST such request; the first requests are grouped by owner, request
+        order kept inside a group; `send` lists their shard indices and is padded with -1 to the number of requests."""
         n = ids.shape[0]
         req = torch.cat([ids[:, 0], ids[:, 2]]) if sample_layout else ids.reshape(-1)
-        owner = req % world
-        order = torch.argsort(owner, stable=True)          # grouped by owner, request order kept inside a group
-        slot = torch.empty_like(order)
-        slot[order] = torch.arange(order.numel())
-        send = torch.div(req[order], world, rounding_mode="floor")
+        m = req.numel()
+        pos = torch.arange(m)
+        if merge:
+            uniq, inv = torch.unique(req, return_inverse=True)
+            first = torch.full((uniq.numel(),), m, dtype=torch.int64).scatter_reduce(0, inv, pos, reduce="amin")[inv]
+        else:
+            first = pos
+        reps = pos[first == pos]                               # the first request of every distinct row, in request order
+        owner = req[reps] % world
+        order = torch.argsort(owner, stable=True)              # grouped by owner, request order kept inside a group
+        place = torch.empty(m, dtype=torch.int64)
+        place[reps[order]] = torch.arange(reps.numel())
+        slot = place[first]
+        send = torch.full((m,), -1, dtype=torch.int64)
+        send[: reps.numel()] = torch.div(req[reps[order]], world, rounding_mode="floor")
         counts = torch.bincount(owner, minlength=world)
         compact = None
         if sample_layout:
@@ -23,7 +35,7 @@ class TorchRowOps:
     def _rows(seg):
         ids, rows, world, rank, local = seg
         if world <= 0:
-            return ids, torch.ones_like(ids, dtype=torch.bool)
+            return ids.clamp(min=0), ids >= 0  # (-1: an entry behind a merged list / "not mine": skipped)
         return torch.div(ids, world, rounding_mode="floor"), (ids % world) == rank
 
     def gather(self, shard, segs, weight=None, weight_sum=None, zero=None, occ=None):
