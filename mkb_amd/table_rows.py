@@ -487,11 +487,14 @@ class TableRowShardedStep:
         if opt is not None and _sampler is None:
             opt.catch_up_sharded(tb.data, info.pool, self.world, self.rank_of_table, want)
             opt._state(tb.data)["caught_up"] = (touched, opt._state(tb.data)["n"])
-        reply = torch.empty((R, D), dtype=torch.float32, device=dev)
+        # (one rank and no forced collectives: the all-to-alls are the identity -- the owner IS the user --, so the rows are
+        # read straight into the compact table and their gradients taken straight from it: no stand-in copies)
+        direct = not _collectives_run(self.world)
+        reply = ent[row0: row0 + R] if direct else torch.empty((R, D), dtype=torch.float32, device=dev)
         ops.gather(tb.data.detach(), [(info.pool, ent[:P], self.world, tb.rank, touched[:P]), (want, reply, 0, 0, None)],
                    weight=weight, weight_sum=bufs["wsum"], zero=grad, occ=self._occ)
         # 2. positive rows to their users, pool block (+ weight sum) completed everywhere
-        w_rows = route.rows_to_requesters(reply, ent[row0:], async_op=True)
+        w_rows = None if direct else route.rows_to_requesters(reply, ent[row0:], async_op=True)
         w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if _collectives_run(self.world) else None
         for w in (w_rows, w_pool):
             if w is not None:
@@ -510,8 +513,8 @@ class TableRowShardedStep:
             bufs["loss"].copy_(loss.reshape(1))
         # 4. pool-row gradients + relation gradient + loss share (+ modulus gradient): one all-reduce; positive-row
         #    gradients back to their owners
-        back = torch.empty((R, D), dtype=torch.float32, device=dev)
-        w_back = route.rows_to_owners(grad[row0:], back, async_op=True)
+        back = grad[row0: row0 + R] if direct else torch.empty((R, D), dtype=torch.float32, device=dev)
+        w_back = None if direct else route.rows_to_owners(grad[row0:], back, async_op=True)
         w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if _collectives_run(self.world) else None
         for w in (w_back, w_sum):
             if w is not None:
