@@ -282,9 +282,18 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
 __global__ __launch_bounds__(256) void rel_fold_kernel(const float *__restrict__ rep, float *__restrict__ g_rel, int copies, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
+    // eight copies' loads at a time (a loop with a run-time trip count waits for every load before it issues the next:
+    // 23 copies were 23 round trips -- 7 us for half a megabyte); added up in copy order
     float s = 0.f;
-    for (int c = 0; c < copies; ++c) s += rep[(int64_t)c * n + e];
-    g_rel[e] += s;
+    const float old = g_rel[e];
+    for (int c0 = 0; c0 < copies; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = rep[(int64_t)min(c0 + k, copies - 1) * n + e];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += c0 + k < copies ? v[k] : 0.f;
+    }
+    g_rel[e] = old + s;
 }
 
 __global__ __launch_bounds__(256) void masked_copy_kernel(const float *__restrict__ src, const uint16_t *__restrict__ cnt,
