@@ -206,6 +206,19 @@ class _Route:
         self.sc = self.rc = self.want = None
         self._host = self._event = self._ready = None
 
+    _ring, _ring_at = {}, 0
+
+    @classmethod
+    def _pinned(cls, n):
+        """A pinned int64 buffer for the counts' read-back, from a small ring (a fresh pinned allocation per step costs the
+        host hundreds of microseconds and may serialise with the device: the read-back then is not there when the next step
+        asks for it).  Four buffers: a route lives for one step and its buffer is consumed at the start of the next."""
+        ring = cls._ring.get(n)
+        if ring is None:
+            ring = cls._ring[n] = [torch.empty(n, dtype=torch.int64, pin_memory=True) for _ in range(4)]
+        cls._ring_at = (cls._ring_at + 1) % 4
+        return ring[cls._ring_at]
+
     @classmethod
     def side_stream(cls, dev):
         side = cls._side.get(dev)
@@ -222,7 +235,7 @@ class _Route:
         work = dist.all_to_all_single(both[tb.world:], both[: tb.world], group=tb.group, async_op=True)
         if both.is_cuda:  # read back beside the compute stream: the host waits for THIS copy only, never for the step's kernels
             side = self.side_stream(both.device)
-            self._host = torch.empty(2 * tb.world, dtype=torch.int64, pin_memory=True)
+            self._host = self._pinned(2 * tb.world)
             with torch.cuda.stream(side):
                 if work is not None:
                     work.wait()
