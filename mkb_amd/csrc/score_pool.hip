@@ -448,12 +448,13 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             // l < K / (npb * halves) of every half are dense; rounded down to whole lanes per chunk (a chunk = every cph-th lane
             // of a half).  Round 3: the same gradients; per step, same box, general vs dense pass:
             // headline 0.242 -> 0.240 ms, WN18RR 0.150 -> 0.143, YAGO3-10 0.206 -> 0.202, TransE-1000 0.183 -> 0.185.  So: on
-            // for the complex-modulus pair function, off for the real-valued ones; MKB_POOL_DENSE=1 / 0 forces it on / off
-            // (read per call: the tests switch it within one process).
+            // for the complex-modulus pair function; the real-valued ones have no dense form (round 4: their ten instantiations
+            // were 0.6 MB of the library for a path that measured slower); MKB_POOL_DENSE=0 switches it off (read per call: the
+            // tests switch it within one process).
             const char *e = getenv("MKB_POOL_DENSE");
             const int cph = 16 / L.pb_halves;
             const int ld = (int)((P / 2) / ((int64_t)npb * L.pb_halves)) / cph * cph;
-            const bool on = e ? e[0] == '1' : cp;
+            const bool on = cp && (e ? e[0] == '1' : true);  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
             if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
         if (L.bwd1) {

@@ -1661,19 +1661,28 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     A2.q_slices = L.q_slices; A2.dim_slices = L.dim_slices; A2.pb_halves = L.pb_halves; A2.tiles_per_wave = L.tiles_per_wave;
     A2.dense_lanes = A.g_blocked ? L.dense_lanes : 0;  // (the dense pass reads the blocked seed layout)
     A2.lds_ids_off = (int)(lds_main / 4);
-    const bool dense = A2.dense_lanes > 0;
+    // the dense form is compiled for the complex-modulus pair function only (plan_launch never asks for it elsewhere: measured
+    // slower for the real-valued models, and ten instantiations of this kernel are 0.6 MB of the library)
+    constexpr bool kHasDense = ModelTraits<MODEL>::cplx_pair;
+    const bool dense = kHasDense && A2.dense_lanes > 0;
+    if (!kHasDense && A2.dense_lanes > 0) return set_error(MKB_ERR_INVALID, "the dense pass is built for complex-modulus models only");
     static LdsOptIn lds_ok[2];  // per instantiation: opt in to more than 64 KB of dynamic LDS once per device
     if (lds > 64 * 1024) {
-        const void *fn = dense ? reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, true>)
-                               : reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, false>);
+        const void *fn = reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, false>);
+        if constexpr (kHasDense)
+            if (dense) fn = reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, true>);
         if (int rc = lds_ok[dense].ensure(fn, 160 * 1024)) return rc;
     }
     const int row_tiles = (A.B + TI - 1) / TI, per_group = kBwd1Waves * L.tiles_per_wave;
     const unsigned groups = (unsigned)((row_tiles + per_group - 1) / per_group);
-    if (dense)
-        hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT, true>), dim3(groups * L.q_slices * L.dim_slices),
-                           dim3(kBwd1Waves * 64), lds, st, A2);
-    else
+    bool launched = false;
+    if constexpr (kHasDense)
+        if (dense) {
+            hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT, true>), dim3(groups * L.q_slices * L.dim_slices),
+                               dim3(kBwd1Waves * 64), lds, st, A2);
+            launched = true;
+        }
+    if (!launched)
         hipLaunchKernelGGL((pool_bwd1_kernel<MODEL, HEAD, KPT, false>), dim3(groups * L.q_slices * L.dim_slices),
                            dim3(kBwd1Waves * 64), lds, st, A2);
     const DxReduce R = make_dx_reduce(A2, KPT, ModelTraits<MODEL>::cplx_pair, (int)groups);

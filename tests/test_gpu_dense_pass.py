@@ -1,6 +1,8 @@
-"""The opt-in DENSE pass of the single-pass pooled backward (pool_bwd1_kernel<..., DENSE>, MKB_POOL_DENSE=1; DESIGN.md
-section 8): the parity cases of tests/test_gpu_pool.py that reach the single-pass backward, re-run with the pass switched on.
-The switch is read by the library at every call, so it can be flipped inside one process."""
+"""The DENSE pass of the single-pass pooled backward (pool_bwd1_kernel<..., DENSE>): the parity cases of
+tests/test_gpu_pool.py that reach the single-pass backward, re-run with MKB_POOL_DENSE=1.  The dense form is compiled for the
+complex-modulus pair function (RotatE) only -- there it is the default, the flag changes nothing; the real-valued models have
+no dense form since round 4 and the TransE / pRotatE cases below check that asking for it is harmless (general pass, same
+gradients).  The switch is read by the library at every call, so it can be flipped inside one process."""
 import numpy as np
 import pytest
 
@@ -47,8 +49,8 @@ def test_dense_pass_config2_full_size():
 
 
 @pytest.mark.parametrize("name,hidden,B,K", [
+    ("RotatE", 250, 2048, 384),    # 768 positions / 4 blocks = 192 per block = 3 halves of 64 (rounded up to 4), dense lanes 16
     ("TransE", 500, 2048, 384),
-    ("pRotatE", 500, 2048, 384),
     ("TransE", 201, 4096, 300),
 ])
 def test_dense_pass_position_blocks_not_a_power_of_two(name, hidden, B, K):
