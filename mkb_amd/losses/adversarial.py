@@ -46,4 +46,6 @@ class Adversarial:
         pos = _hip.contiguous(positive_score, torch.float32)
         neg = _hip.contiguous(negative_score, torch.float32)
         w = _hip.contiguous(weight, torch.float32)
+        if pos.shape[0] == 0:  # the reference divides two empty sums by W = 0 (losses/adversarial.py:28-30): nan, no launch
+            return (pos.sum() + neg.sum() + w.sum()) / w.sum()
         return _AdversarialFn.apply(pos, neg, w, float(self.alpha))

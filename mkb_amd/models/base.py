@@ -194,6 +194,13 @@ class BaseModel(Base):
         mode_id = _hip.mode_id(mode)
         sample = _hip.contiguous(sample, torch.int64)
         cand = None
+        if sample.shape[0] == 0:
+            # an empty batch, as the reference answers it (models/base.py:153-207 + the forward's view): positives -> an empty
+            # [0, 1] score, negatives -> RuntimeError (its `view(B, K, -1)` of zero elements is ambiguous).  No launch.
+            if mode_id != _hip.MODE_DEFAULT:
+                raise RuntimeError("cannot reshape tensor of 0 elements into shape [0, %d, -1]: an empty batch has no negatives to score"
+                                   % (negative_sample.shape[-1] if negative_sample is not None and negative_sample.dim() else 0))
+            return (self.entity_embedding.sum() * 0.0).expand(0, 1).reshape(shape)  # (differentiable: backward adds nothing)
         if VALIDATE_IDS:
             self._launch_id_check(sample, negative_sample if mode_id != _hip.MODE_DEFAULT else None)
         if mode_id != _hip.MODE_DEFAULT:

@@ -155,6 +155,8 @@ class NegativeSampling:
         dev = sample.device
         self._ensure_handle(dev)
         B, K = sample.shape[0], self.size
+        if B == 0:
+            self._empty_batch()
         neg = torch.empty((B, K), dtype=torch.int64, device=dev)
         pool = torch.empty(2 * K, dtype=torch.int64, device=dev)
         pos = torch.empty((B, K), dtype=torch.int32, device=dev)
@@ -228,6 +230,22 @@ class NegativeSampling:
         if rc == _hip.ERR_KEY:
             raise KeyError(msg)
         raise RuntimeError(msg)
+
+    def _empty_batch(self):
+        """An empty batch, as the reference answers it (sampling/negative_sampling.py:166-201): the batch's pool IS drawn, then
+        ``torch.stack`` of no rows raises RuntimeError.  The generator moves on by one pool here as well, so a caller that
+        catches the error stays in step with the reference's stream."""
+        if self.rng == "rocrand":
+            _, (seed, draws) = self.get_state()
+            self.set_state("rocrand", (seed, draws + 1))
+        else:
+            key, pos = self.get_state()
+            rs = np.random.RandomState()
+            rs.set_state(("MT19937", np.asarray(key, dtype=np.uint32), int(pos)))
+            rs.randint(self.n_entity, size=2 * self.size)
+            st = rs.get_state()
+            self.set_state(st[1], int(st[2]))
+        raise RuntimeError("stack expects a non-empty TensorList (an empty batch has no rows to sample negatives for)")
 
     # ---- RNG state (numpy MT19937 key + position), e.g. for checkpoint/resume or multi-GPU replication
     def get_state(self):

@@ -108,6 +108,37 @@ def test_empty_filter_raises_instead_of_hanging():
         ns.check()
 
 
+def test_empty_batch_behaves_like_the_reference():
+    """What the reference answers an empty batch with (probed on the live import, CountriesS1 / RotatE hidden 4): a positive
+    forward -> an empty [0, 1] score; a negative forward -> RuntimeError (view of zero elements); ``generate`` -> RuntimeError
+    (``torch.stack`` of no rows) AFTER the batch's pool was drawn: the next call sees the stream's second pool; the loss of no
+    rows -> nan (0 / 0).  None of it launches a kernel."""
+    from mkb_amd import datasets, losses, models, sampling
+
+    ds = datasets.CountriesS1(batch_size=4, seed=42)
+    m = models.RotatE(hidden_dim=4, entities=ds.entities, relations=ds.relations, gamma=3).cuda()
+    s0 = torch.zeros((0, 3), dtype=torch.long).cuda()
+    out = m(s0)
+    assert tuple(out.shape) == (0, 1)
+    out.sum().backward()  # differentiable, adds nothing
+    assert float(m.entity_embedding.grad.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        m(s0, torch.zeros((0, 5), dtype=torch.long).cuda(), mode="head-batch")
+    assert torch.isnan(losses.Adversarial()(torch.zeros(0, 1).cuda(), torch.zeros(0, 5).cuda(), torch.zeros(0).cuda())).item()
+
+    mk = lambda: sampling.NegativeSampling(size=5, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+    batch = torch.as_tensor(np.asarray(ds.train[:6], dtype=np.int64)).cuda()
+    a, b = mk(), mk()
+    with pytest.raises(RuntimeError, match="non-empty"):
+        a.generate(s0, "head-batch")
+    b.generate(batch, "head-batch")               # b's first pool = the one a's empty call consumed
+    na, nb = a.generate(batch, "tail-batch"), b.generate(batch, "tail-batch")
+    np.testing.assert_array_equal(na.cpu().numpy(), nb.cpu().numpy())
+    rs = np.random.RandomState(42)
+    rs.randint(len(ds.entities), size=10)
+    np.testing.assert_array_equal(na._mkb_pool.pool.cpu().numpy(), rs.randint(len(ds.entities), size=10))
+
+
 def test_pool_drawn_ahead_inside_the_optimizer_launch_is_bit_identical():
     """mkb_adam_rows_catchup(draw_ahead=sampler): the next pool is drawn by one more workgroup of the optimizer's
     catch-up launch instead of the stand-alone kernel.  Negatives, pools and the reported generator state must

@@ -1,0 +1,5 @@
+for rep in 1 2; do for v in "$@"; do
+  for c in headline wn18rr-rotate; do
+    echo -n "$v $c: "; MKB_HIP_LIB=$PWD/variants/lib_$v.so python bench.py --config $c --no-traffic --no-cpu-baseline --mrr-epochs 0 --no-variants --profile-kernel loss --steps 300 --warmup 30 2>/dev/null | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['ms_per_step'],4), round(j['roofline']['avg_kernel_us'],1) if j.get('roofline') else None)"
+  done
+done; done
