@@ -44,6 +44,7 @@ MODEL, DATASET = "RotatE", "fb15k237"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector = fp32 matrix peak (256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz)
 TRANS_PEAK_TOPS = 19.66   # quarter-rate transcendentals: 1024 SIMDs x 8 results/clk x 2.4 GHz
+BF16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense bf16 matrix peak (256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz)
 
 # BASELINE.json configs; the default (and the only one the driver runs) is the headline, configs[2]
 CONFIGS = {
@@ -513,9 +514,9 @@ def roofline_of(res, world, want_traffic):
     # the rocprofv3 name of the class's kernel: taken from the PMC pass when there was one, else spelled from the configuration
     # (template arguments: model id, head-batch, units per lane, dense pass); the internal class name rides along as `class`
     mid = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}.get(MODEL, "?")
-    guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else "mkb::gemm128_f32_mfma_kernel<..> (dQ = G . X)"),
+    guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else "mkb::gemm128_bf16x3_mfma_kernel<true, false, 0, ..> (dQ = G . X)"),
              "pool_fwd": (f"mkb::pool_fwd_tile_kernel<{mid}, true|false, ..>" if MODEL == "RotatE" else f"mkb::pool_fwd_kernel<{mid}, ..>"),
-             "pool_bwd_x": "mkb::gemm128_f32_mfma_kernel<..> (dX = G^T . Q)", "adam": "mkb::adam_rows_catchup_kernel"}.get(prof_kind, prof_kind)
+             "pool_bwd_x": "mkb::gemm128_bf16x3_mfma_kernel<false, false, 0, ..> (dX = G^T . Q)", "adam": "mkb::adam_rows_catchup_kernel"}.get(prof_kind, prof_kind)
     kernel_name = kname or guess
     info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
     if prof_kind == "adam":
@@ -561,6 +562,14 @@ def roofline_of(res, world, want_traffic):
             "note": (f"{label}: " + (f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}"
                                      if mfma else f"{pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop")
                      + "; peak = fp32 vector / matrix rate of MI355X")}
+    if mfma and os.environ.get("MKB_GEMM_BF16X3", "1") != "0":
+        # the product runs on the bf16 matrix pipe: fp32 operands split three ways, six bf16 instructions per fp32 product
+        # (gemm_mfma.h): the algorithmic (fp32-equivalent) rate above is what the step gets; the EXECUTED bf16 rate is 6x it
+        roof["executed_bf16_TFLOPs"] = 6.0 * ach
+        roof["executed_frac_of_bf16_peak"] = 6.0 * ach / BF16_PEAK_TFLOPS
+        roof["note"] += (f"; executed on the bf16 matrix pipe as 6 bf16 products per fp32 product (three-way operand split, results "
+                         f"within ~2e-7 |a||b| of fp32): {6.0 * ach:.0f} TFLOP/s executed = {6.0 * ach / BF16_PEAK_TFLOPS:.3f} of the "
+                         f"{BF16_PEAK_TFLOPS:.0f} TFLOP/s dense bf16 peak")
     if MODEL == "RotatE":
         # ceiling at the instruction rates MEASURED on this part (tools/ubench/trans_rate.hip, profiles/r03_instruction_rates_and_
         # tile_ubench.txt: v_pk_*_f32 2.17 ns, v_sqrt / v_rsq 3.58 ns per wave64 instruction and SIMD, SIMDs saturated): the pair

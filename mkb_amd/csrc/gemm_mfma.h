@@ -25,11 +25,13 @@ namespace mkb {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { GEMM_STORE = 0, GEMM_STORE_AFFINE = 1, GEMM_ATOMIC_ROWS = 2 };
+constexpr bool kGemmBf16x3Default = true;  // MKB_GEMM_BF16X3=0: the fp32-input matrix instruction instead (gemm128_f32_mfma_kernel)
 
 struct GemmArgs {
     const float *A, *B;
     float *C;
     const int64_t *b_idx;   // optional row indirection of B (B_NK: indexed by n; B_KN: indexed by k)
+    int64_t b_rows;         // ... rows of the table b_idx points into (0 = unknown: the bf16 kernel's 32-bit offsets are not used)
     const int64_t *c_idx;   // GEMM_ATOMIC_ROWS: output row m goes to C[c_idx[m]]
     const float *scale_dev; // optional device scalar multiplied into c1 (pRotatE-style), unused for the dot models
     int M, N, K;
@@ -225,7 +227,10 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         for (int e = 0; e < V; ++e) {
             int r, kk;
             coord(A_MK, TM, e, r, kk);
-            const int m = min(m0 + r, G.M - 4), k = min(k0 + kk, A_MK ? k_hi - 4 : k_hi - 1);
+            // (the float4 runs along k for A_MK, along m otherwise: only then must it start four rows before the end.  Rounds 3-4
+            // clamped to M - 4 in both cases: the LAST THREE ROWS of a k-contiguous A -- batch rows B-3 .. B-1 of the score and
+            // dQ products -- were computed from row M - 4; found by comparing against the VALU route on every row)
+            const int m = min(m0 + r, A_MK ? G.M - 1 : G.M - 4), k = min(k0 + kk, A_MK ? k_hi - 4 : k_hi - 1);
             ra[e] = *reinterpret_cast<const float4 *>(G.A + (A_MK ? (int64_t)m * G.lda + k : (int64_t)k * G.lda + m));
         }
 #pragma unroll
@@ -323,6 +328,246 @@ __global__ __launch_bounds__(256) void gemm128_f32_mfma_kernel(GemmArgs G) {
         }
 }
 
+// ---- third kernel: the same 128 x TN tile on the bf16 matrix pipe, fp32 operands split three ways ------------------------
+// gfx950 multiplies bf16 sixteen times faster than fp32 (v_mfma_f32_32x32x16_bf16: 32 x 32 x 16 in 8 passes; the fp32-input
+// v_mfma_f32_32x32x2_f32 needs 16 passes for 32 x 32 x 2).  An fp32 value x is EXACTLY hi + mid + lo with three bf16 numbers
+// (8 significant bits each, rounded to nearest: x - hi and (x - hi) - mid are exact in fp32, lo carries the last rounding), so
+//     a . b = (ah + am + al)(bh + bm + bl)  ~  ah bh + ah bm + am bh + ah bl + al bh + am bm
+// -- the three products left out are below 2^-24 |a||b|, the size of fp32's own rounding -- every kept product of two bf16
+// numbers is exact in fp32 and the sums accumulate in fp32 inside the matrix unit.  Six bf16 instructions do the work of
+// eight fp32 ones at a sixteenth of the passes each: 2.7x the matrix rate for results within ~2e-7 |a||b| per term of the
+// fp32 kernel's (the parity budget is 1e-4).  The operands are split when a K chunk is written to LDS (5.5 VALU operations
+// per value: split3_bf16_pair), three bf16 planes per operand, rows 80 bytes apart (64 bytes of k + 16 of pad: the 16-byte fragment
+// reads of 8 consecutive rows fall on 8 different bank groups).  k-contiguous operands are loaded as before (float4 along k,
+// 8-byte LDS stores); row-contiguous operands are loaded one value per lane and k -- lanes along the rows, coalesced -- so
+// that a lane holds 8 or 16 consecutive k of ONE row and writes them with 16-byte stores (4-byte stores of the float4
+// form land 64 lanes on four banks: tried in round 4 with fp32 fragments, 29 -> 39 us).  One LDS stage (46 / 61 KB), two
+// barriers per chunk: two workgroups share a CU and fill each other's staging phases.  Measured at the ComplEx shape
+// (1024 x 512 x 2000 and its two transposes; fp32 kernel -> this one): score product 26.2 -> 19.7 us, dQ 21.5 -> 20.7,
+// dX 28.8 -> 23.6: these products are short (8-16 chunks per workgroup), what is left is their prologues and epilogues.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBfPitch = 80;  // bytes between rows of a bf16 plane
+
+// two values -> one word per plane (element k in the low half, k + 1 in the high half): v_cvt_pk_bf16_f32 rounds to nearest and
+// packs in one instruction; x - hi and (x - hi) - mid are exact in fp32.  11 VALU operations per pair.
+__device__ __forceinline__ void split3_bf16_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
+}
+
+// one operand's share of a K chunk: ROWS x 32 values per 256 lanes
+template <bool K_MAJOR, int ROWS>
+struct Bf16Stage {
+    static constexpr int NEL = ROWS * 32 / 256;  // values per lane and chunk: 16 (128 rows) or 8 (64 rows)
+    float v[NEL];
+    // k-contiguous: NEL / 4 float4, f = tid + e * 256 -> row f >> 3, k (f & 7) * 4.  row-contiguous: row tid % ROWS, k (tid / ROWS) * NEL + j
+    static constexpr int NROWS = K_MAJOR ? NEL / 4 : 1;  // rows a lane touches (k-contiguous: one per float4)
+    __device__ __forceinline__ static int row_of(int tid, int e) { return K_MAJOR ? (tid + e * 256) >> 3 : tid % ROWS; }
+    __device__ __forceinline__ static int k_of(int tid, int e) {  // chunk-relative k of the lane's e-th float4 / of its first value
+        return K_MAJOR ? ((tid + e * 256) & 7) * 4 : __builtin_amdgcn_readfirstlane(tid / ROWS) * NEL;
+    }
+    // Buffer loads (one descriptor per operand, built from kernel arguments: scalar registers): the address of a load is
+    // descriptor base + voff (per lane, bytes; the same in every K chunk: computed once by the caller) + soff (scalar, bytes):
+    //   k-contiguous:   voff[e] = (row * ld + k of the float4) * 4,   soff = k0 * 4
+    //   row-contiguous: voff[0] = row * 4,                           soff(j) = (row of k0 + kk0 + j) * ld * 4 -- whole waves
+    //     share a k group (ROWS is a multiple of 64), so k is wave-uniform and this is scalar arithmetic
+    // With 64-bit flat addresses the staging of the row-contiguous operands spent more VALU instructions on addresses than on
+    // the split (1500 VALU instructions around 49 matrix instructions per chunk pair).
+    //   (k-contiguous, last chunk of a range: a float4 whose k lies beyond the range is pulled back onto the range's last four
+    //   values -- soff(e) is then per lane; its values are zeroed at the store)
+    template <typename Rsrc, typename SoffFn>
+    __device__ __forceinline__ void load(Rsrc rs, const int (&voff)[NROWS], int tid, SoffFn soff) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        if constexpr (K_MAJOR) {
+#pragma unroll
+            for (int e = 0; e < NEL / 4; ++e) {
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[e] + soff(e), 0, 0);
+                v[4 * e] = __uint_as_float(q.x); v[4 * e + 1] = __uint_as_float(q.y);
+                v[4 * e + 2] = __uint_as_float(q.z); v[4 * e + 3] = __uint_as_float(q.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NEL; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff[0], soff(j), 0));
+        }
+    }
+    // planes: [3][ROWS] rows of kBfPitch bytes; values whose k is not below k_lim (chunk-relative) are written as 0 (FULL: the
+    // whole chunk lies inside the K range -- every chunk but possibly the last: no selects)
+    template <bool FULL>
+    __device__ __forceinline__ void store_as(int tid, unsigned char *planes, int k_lim) const {
+        constexpr int PLANE = ROWS * kBfPitch;
+        auto val = [&](int idx, int k) { return FULL || k < k_lim ? v[idx] : 0.f; };
+        if constexpr (K_MAJOR) {
+#pragma unroll
+            for (int e = 0; e < NEL / 4; ++e) {
+                const int f = tid + e * 256, r = f >> 3, kk = (f & 7) * 4;
+                unsigned h[2], m[2], l[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) split3_bf16_pair(val(4 * e + 2 * j, kk + 2 * j), val(4 * e + 2 * j + 1, kk + 2 * j + 1), h[j], m[j], l[j]);
+                unsigned char *d = planes + r * kBfPitch + kk * 2;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(m[0], m[1]);
+                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(l[0], l[1]);
+            }
+        } else {
+            const int r = tid % ROWS, kk0 = (tid / ROWS) * NEL;
+            unsigned char *d = planes + r * kBfPitch + kk0 * 2;
+#pragma unroll
+            for (int q = 0; q < NEL / 8; ++q) {  // eight values -> one 16-byte store per plane
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    split3_bf16_pair(val(8 * q + 2 * j, kk0 + 8 * q + 2 * j), val(8 * q + 2 * j + 1, kk0 + 8 * q + 2 * j + 1), h[j], m[j], l[j]);
+                *reinterpret_cast<uint4 *>(d + 16 * q) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4 *>(d + 16 * q + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<uint4 *>(d + 16 * q + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(int tid, unsigned char *planes, int k_lim) const {
+        if (k_lim >= 32) store_as<true>(tid, planes, k_lim);  // (workgroup-uniform)
+        else store_as<false>(tid, planes, k_lim);
+    }
+};
+
+template <bool A_MK, bool B_NK, int EPI, int TN>
+__global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
+    constexpr int TM = 128, KC = 32, T = 256, NT = TN / 64;
+    constexpr int PLANE_A = TM * kBfPitch, PLANE_B = TN * kBfPitch;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+    unsigned char *sA = lds_b, *sB = lds_b + 3 * PLANE_A;
+    int *s_idx = reinterpret_cast<int *>(lds_b + 3 * (PLANE_A + PLANE_B));  // [kper_] row ids of the K range (B_KN with b_idx)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (TN / 2);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;
+    __shared__ int s_red[16];
+    int k_cut;
+    if (gemm_depth_cut(G, m0, TM, n0, s_red, k_cut)) return;  // (workgroup-uniform)
+    const int k_lo = blockIdx.z * kper_, k_hi = min(min(G.K, k_cut), k_lo + kper_);
+    if constexpr (!B_NK) {
+        if (G.b_idx) {
+            // (padded to whole chunks with the last id: the loads of a partial chunk need no clamp)
+            for (int k = k_lo + tid; k < k_lo + (k_hi - k_lo + KC - 1) / KC * KC; k += T) s_idx[k - k_lo] = (int)G.b_idx[min(k, k_hi - 1)];
+            __syncthreads();
+        }
+    }
+    typedef Bf16Stage<A_MK, TM> StageA;
+    typedef Bf16Stage<B_NK, TN> StageB;
+    StageA ra;
+    StageB rb;
+    // Operand addresses = descriptor base + 32-bit offsets (the launcher checks that both operands span less than 4 GB).
+    // Indices are clamped into the operands (rows beyond M / N feed outputs nobody stores; k beyond the range is zeroed at the
+    // LDS store); B_NK: the (gathered) rows a lane stages are the same for every K chunk: resolved once.
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G.A), 0, 0xFFFFFFFFu, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G.B), 0, 0xFFFFFFFFu, 0x00020000);
+    int voff_a[StageA::NROWS], voff_b[StageB::NROWS];
+#pragma unroll
+    for (int e = 0; e < StageA::NROWS; ++e) {
+        const int64_t m = min(m0 + StageA::row_of(tid, e), G.M - 1);
+        voff_a[e] = (int)((A_MK ? m * G.lda + StageA::k_of(tid, e) : m) * 4);
+    }
+#pragma unroll
+    for (int e = 0; e < StageB::NROWS; ++e) {
+        const int64_t sel = min(n0 + StageB::row_of(tid, e), G.N - 1);
+        if constexpr (B_NK) voff_b[e] = (int)(((G.b_idx ? G.b_idx[sel] : sel) * G.ldb + StageB::k_of(tid, e)) * 4);
+        else voff_b[e] = (int)(sel * 4);
+    }
+    const int kk0_a = StageA::k_of(tid, 0), kk0_b = StageB::k_of(tid, 0);  // (row-contiguous operands: the wave's first k of a chunk)
+    auto load_into = [&](StageA &ra, StageB &rb, int k0) {
+        ra.load(rs_a, voff_a, tid, [&](int j) {
+            if constexpr (A_MK) return (min(k0 + StageA::k_of(tid, j), k_hi - 4) - StageA::k_of(tid, j)) * 4;
+            else return (int)((int64_t)min(k0 + kk0_a + j, k_hi - 1) * G.lda * 4);
+        });
+        // gathered rows: the wave's NEL row ids of the chunk are consecutive words of s_idx: fetched with 16-byte LDS reads up front
+        // (one read + wait per load put NEL LDS round trips in front of every chunk's loads)
+        int ids[StageB::NEL];
+        if constexpr (!B_NK) {
+            if (G.b_idx) {
+                const int4 *ip = reinterpret_cast<const int4 *>(s_idx + (k0 - k_lo) + kk0_b);
+#pragma unroll
+                for (int q = 0; q < StageB::NEL / 4; ++q) {
+                    const int4 w = ip[q];
+                    ids[4 * q] = w.x; ids[4 * q + 1] = w.y; ids[4 * q + 2] = w.z; ids[4 * q + 3] = w.w;
+                }
+            }
+        }
+        rb.load(rs_b, voff_b, tid, [&](int j) {
+            if constexpr (B_NK) return (min(k0 + StageB::k_of(tid, j), k_hi - 4) - StageB::k_of(tid, j)) * 4;
+            else {
+                const int64_t row = G.b_idx ? (int64_t)__builtin_amdgcn_readfirstlane(ids[j]) : (int64_t)min(k0 + kk0_b + j, k_hi - 1);
+                return (int)(row * G.ldb * 4);
+            }
+        });
+    };
+    auto multiply = [&]() {
+        const unsigned char *pa = sA + (wm + (lane & 31)) * kBfPitch + (lane >> 5) * 16;
+        const unsigned char *pb = sB + (wn + (lane & 31)) * kBfPitch + (lane >> 5) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 fa[2][3], fb[NT][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    fa[a][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pa + p * PLANE_A + a * 32 * kBfPitch + ks * 32));
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    fb[b][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pb + p * PLANE_B + b * 32 * kBfPitch + ks * 32));
+            }
+            // smallest terms first; the (plane of a, plane of b) pairs kept: 0 = hi, 1 = mid, 2 = lo
+            constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[t]], fb[b][PB[t]], acc[a][b], 0, 0, 0);
+        }
+    };
+    // (Round 4 also built a pipelined form -- two LDS stages, two register sets, the next chunk split under this chunk's matrix
+    // instructions, one barrier per chunk -- for launches of one workgroup per CU: slower everywhere (the score product 19.7 ->
+    // 28 us, dX 23.6 -> 35.8, dQ the same): two workgroups per CU filling each other's staging phases beat one that pipelines.)
+    if (k_lo < k_hi) load_into(ra, rb, k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += KC) {
+        ra.store(tid, sA, k_hi - k0);
+        rb.store(tid, sB, k_hi - k0);
+        __syncthreads();
+        if (k0 + KC < k_hi) load_into(ra, rb, k0 + KC);  // the next chunk's loads fly under this chunk's matrix work
+        multiply();
+        __syncthreads();
+    }
+    float *Cz = G.C + (int64_t)blockIdx.z * G.M * G.ldc;  // partial buffer of this K split (z = 0: C itself)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int n = n0 + wn + 32 * b + (lane & 31);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + wm + 32 * a + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < G.M && n < G.N) {
+                    const float v = acc[a][b][reg];
+                    if constexpr (EPI == GEMM_STORE) Cz[(int64_t)m * G.ldc + n] = v;
+                    else if constexpr (EPI == GEMM_STORE_AFFINE) Cz[(int64_t)m * G.ldc + n] = (gridDim.z > 1) ? v : G.c0 + G.c1 * v;
+                    else if (v != 0.f) atomicAdd(G.C + G.c_idx[m] * G.ldc + n, v);
+                }
+            }
+        }
+}
+
 // out[i] = c0 + c1 * sum_z part[z][i]   (fixed order: deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t n,
                                                             int nz, float c0, float c1) {
@@ -389,11 +634,28 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             const size_t lds = (size_t)2 * (128 + tn) * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;  // two stages + row ids
             dim3 grid((unsigned)((G.M + 127) / 128), (unsigned)((G.N + tn - 1) / tn), (unsigned)ks);
             // (two stages of a 128 x 128 tile pair are 66 KB: more than the 64 KB a kernel gets without asking)
+            // the three-way bf16 split on the bf16 matrix pipe (gemm128_bf16x3_mfma_kernel) unless MKB_GEMM_BF16X3=0; read per call
+            const char *bx = getenv("MKB_GEMM_BF16X3");
+            // (its buffer loads address an operand with 32-bit byte offsets: every row it can touch must lie within 4 GB of the base)
+            const int64_t a_span = (A_MK ? (int64_t)G.M * G.lda : (int64_t)G.K * G.lda) * 4;
+            const int64_t b_rows = G.b_idx ? G.b_rows : (B_NK ? (int64_t)G.N : (int64_t)G.K);
+            const bool fits32 = a_span < ((int64_t)1 << 32) && b_rows > 0 && b_rows * G.ldb * 4 < ((int64_t)1 << 32);
+            const bool bf16x3 = fits32 && (bx ? bx[0] == '1' : kGemmBf16x3Default);
+            const size_t lds_bf = (size_t)3 * (128 + tn) * kBfPitch + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
             auto launch128 = [&](auto epi_c, auto tn_c, const GemmArgs &GA) -> int {
                 constexpr int E = decltype(epi_c)::value, TNv = decltype(tn_c)::value;
-                static LdsOptIn grant;  // (one per instantiation of this generic lambda)
+                static LdsOptIn grant[2];  // (per instantiation of this generic lambda and kernel form)
+                if constexpr (E != GEMM_ATOMIC_ROWS) {  // (the scattered product goes through split-K partials: STORE; the direct
+                                                        // atomic epilogue -- a caller without a partial buffer -- keeps the fp32 kernel)
+                    if (bf16x3) {
+                        auto *fn = &gemm128_bf16x3_mfma_kernel<A_MK, B_NK, E, TNv>;
+                        if (int rc = grant[1].ensure(reinterpret_cast<const void *>(fn), lds_bf)) return rc;
+                        hipLaunchKernelGGL(fn, grid, dim3(256), lds_bf, st, GA);
+                        return MKB_OK;
+                    }
+                }
                 auto *fn = &gemm128_f32_mfma_kernel<A_MK, B_NK, E, TNv>;
-                if (int rc = grant.ensure(reinterpret_cast<const void *>(fn), lds)) return rc;
+                if (int rc = grant[0].ensure(reinterpret_cast<const void *>(fn), lds)) return rc;
                 hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, GA);
                 return MKB_OK;
             };

@@ -605,7 +605,7 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
     }
     if (use_mfma(tb)) {  // S = Q . ent[pool]^T on the matrix cores, over the pool positions the row tile uses (cnt masks later)
         GemmArgs g{};
-        g.A = w.Q; g.lda = tb->entity_dim; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
+        g.A = w.Q; g.lda = tb->entity_dim; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool; g.b_rows = tb->n_entity;
         g.C = S; g.ldc = P; g.M = (int)B; g.N = (int)P; g.K = (int)tb->entity_dim; g.c0 = 0.f; g.c1 = 1.f;
         if (cut) { g.depth = w.depth; g.depth_mode = 1; g.n_depth = (int)B; }
         ProfScope ps(MKB_PROF_POOL_FWD, st);
@@ -632,7 +632,7 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
     if (use_mfma(tb)) {
         {   // dQ [B, De] = G [B, P] . ent[pool]
             GemmArgs g{};
-            g.A = w.G; g.lda = P; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool;
+            g.A = w.G; g.lda = P; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool; g.b_rows = tb->n_entity;
             g.C = w.dQ; g.ldc = tb->entity_dim; g.M = (int)B; g.N = (int)tb->entity_dim; g.K = (int)P;
             if (cut) { g.depth = w.depth; g.depth_mode = 2; g.n_depth = (int)B; }  // (G is exactly 0 beyond a row's depth)
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);

@@ -1,0 +1,83 @@
+"""The bf16 matrix-pipe form of the pooled GEMMs (gemm128_bf16x3_mfma_kernel, gemm_mfma.h): fp32 operands split into three bf16
+numbers each, six bf16 products per fp32 product.  It is the default of the GEMM-shaped models (ComplEx, DistMult); the parity
+cases of tests/test_gpu_pool.py therefore already run through it against the oracle.  Here: the two forms of the kernel on the
+same inputs (MKB_GEMM_BF16X3 is read per call), and the edge shapes of the staging code (K ranges that end inside a chunk, rows
+and columns that end inside a tile, depth cuts)."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import test_gpu_pool as T  # noqa: E402  (tests/ is on sys.path: conftest.py)
+
+
+def _grads(name, hidden, B, K, flag, mode, seed=3, no_mfma=False):
+    from mkb_amd.fused import FusedTrainStep
+
+    ds, m, tb, ns, train = T._setup("Fb15k237", name, hidden, B, K, gamma=9.0)
+    idx = torch.as_tensor(np.random.RandomState(seed).randint(len(train), size=B))
+    s = train[idx].cuda()
+    w = (torch.rand(B, generator=torch.Generator().manual_seed(seed)) + 0.1).cuda()
+    neg = ns.generate(s, mode)
+    old = os.environ.get("MKB_GEMM_BF16X3")
+    os.environ["MKB_GEMM_BF16X3"] = flag
+    if no_mfma:
+        os.environ["MKB_POOL_NO_MFMA"] = "1"  # the lane-owns-dims VALU kernels instead of the matrix cores (read per call)
+    try:
+        m.zero_grad(set_to_none=True)
+        loss = FusedTrainStep(m, alpha=1.0)(s, w, neg, mode)
+        return float(loss), m.entity_embedding.grad.cpu().numpy().copy(), m.relation_embedding.grad.cpu().numpy().copy()
+    finally:
+        os.environ.pop("MKB_POOL_NO_MFMA", None)
+        if old is None:
+            os.environ.pop("MKB_GEMM_BF16X3", None)
+        else:
+            os.environ["MKB_GEMM_BF16X3"] = old
+
+
+@pytest.mark.parametrize("name", ["ComplEx", "DistMult"])
+@pytest.mark.parametrize("mode", ["head-batch", "tail-batch"])
+def test_bf16x3_equals_the_fp32_matrix_instruction_on_the_headline_shape(name, mode):
+    """hidden 1000, K 256, B 1024: scores are sums of 2000 / 1000 products of magnitude ~1e-4; the three dropped cross terms of
+    the split are below 2^-24 of a product: the two forms agree to ~1e-7 of the gradients' scale."""
+    l1, e1, r1 = _grads(name, 1000, 1024, 256, "1", mode)
+    l0, e0, r0 = _grads(name, 1000, 1024, 256, "0", mode)
+    assert abs(l1 - l0) <= 2e-7 * max(1.0, abs(l0))
+    scale_e, scale_r = np.abs(e0).max(), np.abs(r0).max()
+    assert scale_e > 0 and scale_r > 0
+    np.testing.assert_allclose(e1, e0, rtol=0, atol=2e-6 * scale_e)
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=2e-6 * scale_r)
+
+
+@pytest.mark.parametrize("name,hidden,B,K", [
+    # (the 128-row tile kernels take products of >= 24 tiles with 4-aligned sizes; smaller ones use the 64 x 64 fp32 kernel)
+    ("ComplEx", 1030, 1000, 256),   # De 2060 = 64 chunks + 12: the last chunk of the score product's K range is partial; 2060 columns
+                                    # end inside a column tile of dQ / dX; 1000 rows end inside a row tile
+    ("DistMult", 1500, 1020, 250),  # 500 pool positions: dQ's K range ends inside a chunk, dX's row tiles end inside a tile
+    ("ComplEx", 500, 2048, 384),    # 768 pool positions: the depth cuts drop whole tiles and shorten K ranges
+])
+def test_bf16x3_edge_shapes_equal_the_fp32_form(name, hidden, B, K):
+    for mode in ("head-batch", "tail-batch"):
+        l1, e1, r1 = _grads(name, hidden, B, K, "1", mode, seed=5)
+        l0, e0, r0 = _grads(name, hidden, B, K, "0", mode, seed=5)
+        assert abs(l1 - l0) <= 2e-7 * max(1.0, abs(l0))
+        np.testing.assert_allclose(e1, e0, rtol=0, atol=2e-6 * max(np.abs(e0).max(), 1e-30))
+        np.testing.assert_allclose(r1, r0, rtol=0, atol=2e-6 * max(np.abs(r0).max(), 1e-30))
+
+
+@pytest.mark.parametrize("name", ["ComplEx", "DistMult"])
+@pytest.mark.parametrize("flag", ["1", "0"])
+def test_matrix_route_equals_the_valu_route_on_every_row(name, flag):
+    """Both forms of the 128-row tile kernel against the VALU kernels of the pooled path, EVERY row of the table gradient at
+    the headline shape.  (The oracle comparisons of tests/test_gpu_pool.py at this size look at a 128-row slice of the batch;
+    rounds 3-4 computed the last three batch rows of the score and dQ products from row B - 4 -- a row clamp meant for the
+    row-contiguous operand layout -- and nothing looked there.)"""
+    for mode in ("head-batch", "tail-batch"):
+        l1, e1, r1 = _grads(name, 1000, 1024, 256, flag, mode)
+        l0, e0, r0 = _grads(name, 1000, 1024, 256, flag, mode, no_mfma=True)
+        assert abs(l1 - l0) <= 2e-7 * max(1.0, abs(l0))
+        np.testing.assert_allclose(e1, e0, rtol=0, atol=3e-6 * np.abs(e0).max())
+        np.testing.assert_allclose(r1, r0, rtol=0, atol=3e-6 * np.abs(r0).max())
