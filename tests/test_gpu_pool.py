@@ -10,6 +10,13 @@ MODELS = ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"]
 ATOL = 1e-4
 
 
+def _grad_close(got, ref, rtol=0.0, rel=2e-4):
+    """Gradients against the oracle: the absolute 1e-5 of the small-shape tests, or `rel` of the reference's largest entry where
+    that is tighter -- at the full-size shapes the entries are ~1e-8 .. 1e-6 and an absolute 1e-5 would accept anything."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=min(1e-5, rel * max(float(np.abs(ref).max()), 1e-30)))
+
+
 def _setup(cls, name, hidden, B, K, gamma=6.0, seed=0):
     from mkb_amd import datasets, models, sampling
     from oracle import scoring
@@ -49,8 +56,8 @@ def test_pooled_forward_backward_equals_general_and_oracle(name, mode):
         err.backward()
         np.testing.assert_allclose(err.item(), ref["loss"].item(), rtol=0, atol=1e-5)
         got[tag] = (m.entity_embedding.grad.cpu().numpy().copy(), m.relation_embedding.grad.cpu().numpy().copy())
-        np.testing.assert_allclose(got[tag][0], ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(got[tag][1], ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(got[tag][0], ref["g_ent"].numpy())
+        _grad_close(got[tag][1], ref["g_rel"].numpy(), rtol=1e-4)
         if name == "pRotatE":
             np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
     ns.check()
@@ -84,8 +91,8 @@ def test_fused_step_vs_oracle_real_graphs(cls, name, hidden, B, K):
         np.testing.assert_allclose(step.positive_score.cpu().numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy())
+        _grad_close(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4)
         if name == "pRotatE":
             np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
     ns.check()
@@ -187,8 +194,8 @@ def test_full_size_fused_step_gradients_vs_oracle_on_a_128_row_slice(name):
         np.testing.assert_allclose(step.positive_score.cpu()[rows].numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(step.negative_score.cpu()[rows].numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy())
+        _grad_close(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4)
     ns.check()
 
 
@@ -229,8 +236,8 @@ def test_headline_full_size_every_row_weighted_vs_oracle():
         np.testing.assert_allclose(got_pos[rows].numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(got_neg[rows].numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
     np.testing.assert_allclose(loss.item(), total, rtol=0, atol=1e-5)
-    np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), g_ent.numpy(), rtol=0, atol=1e-5)
-    np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), g_rel.numpy(), rtol=1e-4, atol=1e-5)
+    _grad_close(m.entity_embedding.grad.cpu().numpy(), g_ent.numpy())
+    _grad_close(m.relation_embedding.grad.cpu().numpy(), g_rel.numpy(), rtol=1e-4)
 
 
 def _weighted_slice_step(cls, name, hidden, B, K, n_rows, gamma, alpha, seed=11):
@@ -264,8 +271,8 @@ def _weighted_slice_step(cls, name, hidden, B, K, n_rows, gamma, alpha, seed=11)
         np.testing.assert_allclose(step.positive_score.cpu()[rows].numpy(), ref["pos"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(step.negative_score.cpu()[rows].numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy())
+        _grad_close(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4)
         if name == "pRotatE":
             np.testing.assert_allclose(m.modulus.grad.cpu().numpy(), ref["g_modulus"].numpy(), rtol=1e-4)
     ns.check()
@@ -580,8 +587,8 @@ def test_fused_step_edge_shapes_with_wrapping_rows(name, B, K, hidden):
         ref = scoring.train_step_grads(tb, s.cpu(), neg.cpu(), w.cpu(), mode, 0.5, fast_norm=True)
         np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy())
+        _grad_close(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4)
     assert wrapped, "the test is meant to exercise multiplicities > 1"
 
 
@@ -614,8 +621,8 @@ def test_large_pools_run_on_the_pooled_kernels(name, hidden, B, K):
         loss = step(s, w, neg, mode)
         np.testing.assert_allclose(step.negative_score.cpu().numpy(), ref["neg"].numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(m.entity_embedding.grad.cpu().numpy(), ref["g_ent"].numpy())
+        _grad_close(m.relation_embedding.grad.cpu().numpy(), ref["g_rel"].numpy(), rtol=1e-4)
     ns.check()
 
 

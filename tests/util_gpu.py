@@ -43,3 +43,12 @@ def random_problem(name, N, R, hidden, B, K, seed, gamma=6.0):
 
 
 from util_gpu_tables import headline_tables  # noqa: E402,F401  (re-exported for the GPU tests)
+
+
+def grad_close(got, ref, rtol=0.0, rel=2e-4):
+    """Gradients against a reference: absolute 1e-5, or `rel` of the reference's largest entry where that is tighter (at the
+    full-size shapes the entries are ~1e-8 .. 1e-6: an absolute 1e-5 would accept anything)."""
+    import numpy as np
+
+    got, ref = np.asarray(got), np.asarray(ref)
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=min(1e-5, rel * max(float(np.abs(ref).max()), 1e-30)))
