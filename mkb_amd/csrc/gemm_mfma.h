@@ -611,8 +611,13 @@ __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__rest
 // tail: non-null = the caller folds a split-K reduction / scatter into its next launch (GemmTail, common.h): it is described
 // there instead of being launched (kind 0 when the product needed none).
 template <bool A_MK, bool B_NK, int EPI>
-static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr, int want_wg = 0) {
+// slices_cap > 0 (STORE epilogue): the caller's consumer adds up to slices_cap partial products itself -- C is [slices][M][ldc];
+// a K split then writes its partials straight there (no partial buffer, no reduction launch) and *slices_used says how many.
+static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr, int want_wg = 0,
+                       int slices_cap = 0, int *slices_used = nullptr) {
     if (tail) tail->kind = 0;
+    const bool to_slices = slices_cap > 0 && EPI == GEMM_STORE && slices_used;
+    if (slices_used) *slices_used = 1;
     {   // 128 x 128 / 128 x 64 tiles (4 / 2 accumulators per wave) when the operands allow 16-byte loads
         static const bool off = getenv("MKB_GEMM_NO128") != nullptr;  // A/B switch
         const bool al = (((uintptr_t)G.A | (uintptr_t)G.B) & 15) == 0 && G.lda % 4 == 0 && G.ldb % 4 == 0 && G.M % 4 == 0 &&
@@ -627,8 +632,9 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             // each SIMD's matrix pipe idle during its staging; measured 37 -> 29 us, the split-K sum rides the loss rows anyway)
             static const int env_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 0;  // experiment knob
             const int min_wg = env_wg ? env_wg : (want_wg ? want_wg : 200);
-            while (tiles * ks < min_wg && ks < 8 && G.K / (ks * 2) >= 96) ks *= 2;
+            while (tiles * ks < min_wg && ks < 8 && G.K / (ks * 2) >= 96 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
             G.ksplit = ks;
+            if (to_slices) *slices_used = ks;
             float *final_c = G.C;
             const int tn = narrow ? 64 : 128;
             const size_t lds = (size_t)2 * (128 + tn) * 33 * 4 + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;  // two stages + row ids
@@ -673,10 +679,10 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
                 MKB_LAUNCH_CHECK();
                 return MKB_OK;
             }
-            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) G.C = partials;
+            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS && !to_slices) G.C = partials;
             typedef std::integral_constant<int, EPI> epi_t;
             if (int rc = narrow ? launch128(epi_t{}, tn64_t{}, G) : launch128(epi_t{}, tn128_t{}, G)) return rc;
-            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
+            if (ks > 1 && EPI != GEMM_ATOMIC_ROWS && !to_slices) {
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
                 if (tail) *tail = GemmTail{1, partials, final_c, nullptr, G.M, G.N, ks, G.ldc, n, c0, c1, nullptr, 0};
@@ -690,16 +696,17 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
     const bool half = tiles64 < 256;
     const int tiles = half ? ((G.M + 31) / 32) * ((G.N + 63) / 64) : tiles64;
     int ks = 1;
-    if (EPI == GEMM_ATOMIC_ROWS || partials) {
-        while (tiles * ks < 768 && ks < 8 && G.K / (ks * 2) >= 128) ks *= 2;
+    if (EPI == GEMM_ATOMIC_ROWS || partials || to_slices) {
+        while (tiles * ks < 768 && ks < 8 && G.K / (ks * 2) >= 128 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
     }
     G.ksplit = ks;
+    if (to_slices) *slices_used = ks;
     float *final_c = G.C;
-    if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) G.C = partials;
+    if (ks > 1 && EPI != GEMM_ATOMIC_ROWS && !to_slices) G.C = partials;
     dim3 grid((unsigned)((G.M + (half ? 31 : 63)) / (half ? 32 : 64)), (unsigned)((G.N + 63) / 64), (unsigned)ks);
     if (half) hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_MK, B_NK, EPI, 32>), grid, dim3(128), 0, st, G);
     else hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_MK, B_NK, EPI, 64>), grid, dim3(256), 0, st, G);
-    if (ks > 1 && EPI != GEMM_ATOMIC_ROWS) {
+    if (ks > 1 && EPI != GEMM_ATOMIC_ROWS && !to_slices) {
         const int64_t n = (int64_t)G.M * G.ldc;
         const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);

@@ -477,7 +477,7 @@ static Workspace carve(void *ws, int64_t B, int64_t P, int64_t De, const PoolLau
     size_t off = 0;
     auto take = [&](size_t n) { void *r = p ? p + off : nullptr; off += align256(n); return (float *)r; };
     w.Q = take((size_t)B * De * 4);
-    w.dQ = take((size_t)L.q_slices * B * De * 4);
+    w.dQ = take((size_t)(L.mfma ? kMfmaDqSlices : L.q_slices) * B * De * 4);  // (MFMA route: room for the dQ product's K split)
     // gradient seeds: plain [B, P], or the tile-blocked layout of the single-pass backward (rows padded to tiles of 8,
     // positions to blocks * halves * 64 slots)
     const size_t g_plain = (size_t)B * P, g_blocked = L.bwd1 ? (size_t)((B + 7) / 8) * L.q_slices * L.pb_halves * 64 * 8 : 0;
@@ -623,9 +623,11 @@ static int pooled_fwd(const mkb_tables_t *tb, bool head, const int64_t *sample, 
     return launcher_of(tb->model)(0, head, L, A, st);
 }
 
+// dq_slices (out): how many [B, De] partial products the dQ buffer holds (the consumer -- row / query backward -- adds them up)
 static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, const int64_t *sample, const int64_t *pool,
                       const uint16_t *cnt, int64_t B, int64_t P, const Workspace &w, const PoolLaunch &L, hipStream_t st,
-                      bool chain_queries = true, DxReduce *dx_out = nullptr, GemmTail *x_tail = nullptr) {
+                      bool chain_queries = true, DxReduce *dx_out = nullptr, GemmTail *x_tail = nullptr, int *dq_slices = nullptr) {
+    int dq_used = L.q_slices;
     if (x_tail) x_tail->kind = 0;
     static const bool no_cut = getenv("MKB_GEMM_NO_DEPTH") != nullptr;
     const bool cut = use_mfma(tb) && !no_cut;  // w.depth was written by this call's row_fwd / query_build
@@ -636,7 +638,9 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             g.C = w.dQ; g.ldc = tb->entity_dim; g.M = (int)B; g.N = (int)tb->entity_dim; g.K = (int)P;
             if (cut) { g.depth = w.depth; g.depth_mode = 2; g.n_depth = (int)B; }  // (G is exactly 0 beyond a row's depth)
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
-            if (int rc = launch_gemm<true, false, GEMM_STORE>(g, st, w.gemm_part)) return rc;
+            // a K split of this product leaves its partials in the dQ slices: the row backward sums them (it does so for the
+            // VALU route's position blocks anyway) instead of a reduction launch in between (DistMult: 6.5 us)
+            if (int rc = launch_gemm<true, false, GEMM_STORE>(g, st, w.gemm_part, nullptr, 0, kMfmaDqSlices, &dq_used)) return rc;
         }
         {   // g_ent[pool[p]] += (G^T [P, B] . Q [B, De])[p]
             GemmArgs g{};
@@ -667,9 +671,10 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
             if (int rc = launcher_of(tb->model)(2, head, L, A, st)) return rc;
         }
     }
+    if (dq_slices) *dq_slices = dq_used;
     if (chain_queries) {
         RowArgs ra{tb->ent, tb->rel, sample, w.dQ, gr->g_ent, gr->g_rel, tb->entity_dim, tb->relation_dim, tb->hidden_dim,
-                   (int)B, L.q_slices, tb->phase_div};
+                   (int)B, dq_used, tb->phase_div};
         if (int rc = dispatch_query_bwd(tb, head, ra, B, st)) return rc;
     }
     return MKB_OK;
@@ -797,7 +802,7 @@ static int pool_step_bwd(const mkb_tables_t *tb, const mkb_grads_t *gr, const in
     // backward (pipeline.py:236): pooled negatives, then the positive pair and both query chains in one row kernel
     static const bool no_fold = getenv("MKB_GEMM_NO_FOLD") != nullptr;
     if (int rc = pooled_bwd(tb, head, gr, sample, pool, cnt, B, P, w, L, st, /*chain_queries=*/false, L.bwd1 ? &ra.dx : nullptr,
-                            no_fold ? nullptr : &ra.sc)) return rc;
+                            no_fold ? nullptr : &ra.sc, &ra.nslices)) return rc;
     ra.dx.occ = ra.occ;  // (the dx reduction riding this launch writes pool rows: exclusive ones without atomics)
     ra.grads_clear = gr->rows_clear ? 1 : 0;
     ra.dx.clear = ra.grads_clear;

@@ -38,6 +38,7 @@ constexpr int kDense = 6;   // a streamed item used by >= kDense of the tile's 8
 constexpr int kSlab = 16;   // positions per cross-wave reduction batch (forward)
 constexpr int kMaxP = 2048; // pool positions supported (= the device sampler's limit, size <= 1024)
 constexpr int kMaxSlices = 8;
+constexpr int kMfmaDqSlices = 2;  // MFMA route: dQ partial products a K split of G . X may leave for the row backward to add up
 
 struct DxReduce;
 
