@@ -499,6 +499,29 @@ def test_device_ranking_equals_reference_route(name):
     assert fast_rel == slow_rel, (fast_rel, slow_rel)  # relation ranking: device searchsorted filter vs TestDatasetRelation
 
 
+@pytest.mark.parametrize("name", ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"])
+def test_device_ranking_at_the_headline_size_equals_reference_route(name):
+    """The same comparison on FB15k-237 with hidden 1000 (14,541 candidates per query, the tiled all-entity forward at its
+    full row length): 96 test triples, both modes.  At this size neighbouring candidates' scores are ~1e-5 apart and the two
+    routes sum 1000-2000 terms in different orders, so single ranks may swap: the means must agree closely, which a wrong
+    tile or a mis-addressed block of entities (hundreds of ranks per query) would not survive."""
+    from mkb_amd import datasets, evaluation, models
+
+    ds = datasets.Fb15k237(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(5)
+    m = getattr(models, name)(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9).cuda().eval()
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=32,
+                               device="cuda", num_workers=0)
+    test = ds.test[:96]
+    fast = ev.eval(model=m, dataset=test)
+    ev.force_reference_path = True
+    slow = ev.eval(model=m, dataset=test)
+    assert abs(fast["MR"] - slow["MR"]) <= 0.002 * slow["MR"] + 0.5, (fast, slow)
+    assert abs(fast["MRR"] - slow["MRR"]) <= 2e-3, (fast, slow)
+    for k in ("HITS@1", "HITS@3", "HITS@10"):
+        assert abs(fast[k] - slow[k]) <= 0.011, (fast, slow)
+
+
 @pytest.mark.parametrize("name,hidden,world,table", [("RotatE", 48, 2, "small"), ("ComplEx", 32, 4, "small"),
                                                       ("TransE", 500, 2, "small"), ("pRotatE", 40, 2, "small"),
                                                       ("DistMult", 37, 3, "small"), ("RotatE", 24, 2, "big"),
