@@ -81,3 +81,47 @@ def test_matrix_route_equals_the_valu_route_on_every_row(name, flag):
         assert abs(l1 - l0) <= 2e-7 * max(1.0, abs(l0))
         np.testing.assert_allclose(e1, e0, rtol=0, atol=3e-6 * np.abs(e0).max())
         np.testing.assert_allclose(r1, r0, rtol=0, atol=3e-6 * np.abs(r0).max())
+
+
+def test_training_with_either_matrix_form_reaches_the_same_model():
+    """40 fused steps of ComplEx hidden 1000 (FB15k-237, K 256, B 1024) with the row-lazy optimizer, once with each form of the
+    tile kernel: the same loss trajectory and the same tables (Adam divides a gradient by its own running magnitude, so the
+    forms' ~1e-7 relative differences stay ~1e-7 of a step)."""
+    from mkb_amd import datasets, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    def run(flag):
+        old = os.environ.get("MKB_GEMM_BF16X3")
+        os.environ["MKB_GEMM_BF16X3"] = flag
+        try:
+            ds = datasets.Fb15k237(batch_size=1024, shuffle=False, seed=42, num_workers=0)
+            torch.manual_seed(42)
+            m = models.ComplEx(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9.0).cuda()
+            ns = sampling.NegativeSampling(size=256, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
+            opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=5e-3, lazy_rows=True)
+            step = FusedTrainStep(m, alpha=1.0)
+            train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+            w = torch.ones(1024, device="cuda")
+            losses = []
+            for it in range(40):
+                s = train[it * 1024: (it + 1) * 1024].contiguous()
+                losses.append(step.sampled(s, w, ns, "head-batch" if it % 2 == 0 else "tail-batch"))
+                opt.step()
+                opt.zero_grad()
+            opt.flush()
+            return torch.stack(losses).cpu().numpy(), m.entity_embedding.detach().cpu().numpy(), m.relation_embedding.detach().cpu().numpy()
+        finally:
+            if old is None:
+                os.environ.pop("MKB_GEMM_BF16X3", None)
+            else:
+                os.environ["MKB_GEMM_BF16X3"] = old
+
+    l1, e1, r1 = run("1")
+    l0, e0, r0 = run("0")
+    assert l0[-1] < l0[0] - 1e-4, (l0[0], l0[-1])  # (it trains)
+    np.testing.assert_allclose(l1, l0, rtol=0, atol=5e-6)
+    # lr = 5e-3: an element moves ~5e-3 per step it is touched; fp32 atomics order the sums differently run to run, and Adam
+    # turns a sum that cancels to exactly 0 in one order and to a residue in the other into a full step (tests/test_gpu_defer.py)
+    for a, b in ((e1, e0), (r1, r0)):
+        diff = np.abs(a - b)
+        assert int((diff > 1e-4).sum()) <= 64 and float(diff.max()) < 5e-2, (int((diff > 1e-4).sum()), float(diff.max()))
