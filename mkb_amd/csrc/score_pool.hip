@@ -324,9 +324,15 @@ static int units_of(const mkb_tables_t *tb) { return tb->model == MKB_ROTATE ? t
 // many workgroups share a row tile / position tile so that the grid fills 256 CUs with 16-32 waves each.
 // ComplEx / DistMult: the pair function is a dot product, so the pooled block is three dense fp32 GEMMs on the matrix
 // cores (gemm_mfma.h) instead of the lane-owns-dims VALU kernels.  MKB_POOL_NO_MFMA=1 keeps the VALU kernels (A/B).
+// (The two per-call switches -- MKB_POOL_NO_MFMA, MKB_POOL_DENSE -- change the workspace layout.  Callers cache a workspace
+// per table shape, so mkb_pool_step_workspace_bytes reports the LARGEST layout over the switches' settings: g_force_* let it
+// ask pick_config for each.  Found in round 4 by filling freed device memory with NaN between calls: a workspace sized for the
+// matrix route was handed to the VALU route of the same shape -- tests that flipped the switch had been reading and writing past it.)
+static thread_local int g_force_mfma = -1, g_force_dense = -1;  // -1: as the environment says
+
 static bool use_mfma(const mkb_tables_t *tb) {
     const char *e = getenv("MKB_POOL_NO_MFMA");  // read per call: the tests switch it within one process
-    const bool off = e && e[0] == '1';
+    const bool off = g_force_mfma >= 0 ? g_force_mfma == 0 : (e && e[0] == '1');
     return !off && (tb->model == MKB_COMPLEX || tb->model == MKB_DISTMULT) && tb->entity_dim >= 16;
 }
 
@@ -454,7 +460,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             const char *e = getenv("MKB_POOL_DENSE");
             const int cph = 16 / L.pb_halves;
             const int ld = (int)((P / 2) / ((int64_t)npb * L.pb_halves)) / cph * cph;
-            const bool on = cp && (e ? e[0] == '1' : true);  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
+            const bool on = cp && (g_force_dense >= 0 ? g_force_dense == 1 : (e ? e[0] == '1' : true));  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
             if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
         if (L.bwd1) {
@@ -704,9 +710,22 @@ extern "C" int mkb_pool_supported(const mkb_tables_t *tb, int64_t B, int64_t K) 
 }
 
 extern "C" int64_t mkb_pool_step_workspace_bytes(const mkb_tables_t *tb, int64_t B, int64_t K) {
+    if (!tb || B <= 0 || K <= 0) return 0;
+    int64_t best = 0;
+    bool any = false;
+    for (int fm = 0; fm <= 1; ++fm)
+        for (int fd = 0; fd <= 1; ++fd) {  // the largest layout over the per-call switches (see g_force_mfma)
+            PoolLaunch L;
+            g_force_mfma = fm; g_force_dense = fd;
+            const bool ok = pick_config(tb, B, 2 * K, L);
+            const int64_t n = ok ? (int64_t)carve(nullptr, B, 2 * K, tb->entity_dim, L).bytes : 0;
+            g_force_mfma = -1; g_force_dense = -1;
+            any = any || ok;
+            if (n > best) best = n;
+        }
     PoolLaunch L;
-    if (!tb || B <= 0 || K <= 0 || !pick_config(tb, B, 2 * K, L)) return 0;
-    return (int64_t)carve(nullptr, B, 2 * K, tb->entity_dim, L).bytes;
+    if (!pick_config(tb, B, 2 * K, L)) return 0;  // (the shape must be supported as the environment stands)
+    return any ? best : 0;
 }
 
 extern "C" int mkb_pool_score_fwd(const mkb_tables_t *tb, const int64_t *sample, const int64_t *pool, const uint16_t *cnt,

@@ -125,3 +125,28 @@ def test_training_with_either_matrix_form_reaches_the_same_model():
     for a, b in ((e1, e0), (r1, r0)):
         diff = np.abs(a - b)
         assert int((diff > 1e-4).sum()) <= 64 and float(diff.max()) < 5e-2, (int((diff > 1e-4).sum()), float(diff.max()))
+
+
+def test_switching_routes_in_one_process_on_dirty_device_memory():
+    """The per-call switches change the workspace layout while callers cache one workspace per table shape: the size the
+    library reports must cover every setting.  Freed device memory is filled with NaN first, so that a route reading (or a test
+    trusting) bytes it never wrote shows up -- in round 4 exactly this sequence (matrix route, then MKB_POOL_NO_MFMA=1 on the
+    same shape) ran past a workspace sized for the matrix route: a memory access fault on dirty memory, silence on fresh pages
+    (tools/_poison_check.py runs the long form over all five models)."""
+    def poison():
+        blocks = [torch.full((128 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(6)]  # 3 GB
+        torch.cuda.synchronize()
+        del blocks
+
+    ref = _grads("DistMult", 1000, 1024, 256, "1", "head-batch")
+    poison()
+    a = _grads("DistMult", 1000, 1024, 256, "1", "head-batch")
+    poison()
+    b = _grads("DistMult", 1000, 1024, 256, "1", "head-batch", no_mfma=True)
+    poison()
+    c = _grads("DistMult", 1000, 1024, 256, "0", "head-batch")
+    for got in (a, b, c):
+        assert np.isfinite(got[1]).all() and np.isfinite(got[2]).all()
+        assert abs(got[0] - ref[0]) <= 1e-6
+        np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=3e-6 * np.abs(ref[1]).max())
+        np.testing.assert_allclose(got[2], ref[2], rtol=0, atol=3e-6 * np.abs(ref[2]).max())
