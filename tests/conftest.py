@@ -36,3 +36,21 @@ def liboracle():
     if not so.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
     return ctypes.CDLL(str(so))
+
+
+@pytest.fixture(autouse=True)
+def _dirty_device_memory(request):
+    """MKB_TEST_DIRTY_MEMORY=<GB>: before every -m gpu test, fill that much device memory with NaN and free it, so that the
+    allocator hands the test dirty blocks instead of the zero pages of a fresh process (a kernel that reads bytes nobody wrote
+    -- or runs past a buffer -- is silent on zero pages).  Off by default (it adds ~0.1 s per test)."""
+    import os
+
+    gb = os.environ.get("MKB_TEST_DIRTY_MEMORY")
+    if gb and request.node.get_closest_marker("gpu") is not None:
+        import torch
+
+        if torch.cuda.is_available():
+            blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(max(1, int(float(gb))))]
+            torch.cuda.synchronize()
+            del blocks
+    yield
