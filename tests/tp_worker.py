@@ -20,6 +20,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
+    __import__("util_gpu").dirty_device_memory(0.5)  # (MKB_TEST_DIRTY_MEMORY: NaN-filled freed memory instead of zero pages)
     ds = (datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
 

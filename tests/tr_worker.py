@@ -25,6 +25,7 @@ def main():
     # MKB_ROWS_FORCE_COLLECTIVES=1, which keeps the step from short-circuiting them: tests/test_gpu_rccl_world1.py)
     backend = os.environ.get("MKB_TR_BACKEND", "gloo")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
+    __import__("util_gpu").dirty_device_memory(0.5)  # (MKB_TEST_DIRTY_MEMORY: NaN-filled freed memory instead of zero pages)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
     else:

@@ -52,3 +52,16 @@ def grad_close(got, ref, rtol=0.0, rel=2e-4):
 
     got, ref = np.asarray(got), np.asarray(ref)
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=min(1e-5, rel * max(float(np.abs(ref).max()), 1e-30)))
+
+
+def dirty_device_memory(scale=1.0):
+    """MKB_TEST_DIRTY_MEMORY=<GB>: fill that much (x scale) device memory with NaN and free it (see tests/conftest.py); the
+    worker processes of the multi-process tests call this once at their start."""
+    import os
+
+    gb = os.environ.get("MKB_TEST_DIRTY_MEMORY")
+    if gb and torch.cuda.is_available():
+        n = max(1, int(float(gb) * scale))
+        blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        del blocks
