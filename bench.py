@@ -642,6 +642,9 @@ def main():
                          "exchange); 'rows' = batch-row data parallel with sparse gradient all-reduce")
     ap.add_argument("--force-parallelism", action="store_true",
                     help="N=1: run the table-rows code path on the one GPU (world 1, no collective): the per-rank compute of that path")
+    ap.add_argument("--dirty-memory", type=float, default=0.0, metavar="GB",
+                    help="fill that much device memory with NaN and free it before anything is built: the run then works on dirty "
+                         "allocator blocks instead of a fresh process's zero pages (loss / MRR must not change)")
     ap.add_argument("--rccl-world1", action="store_true",
                     help="N=1: the table-rows code path with a world-1 `nccl` process group and MKB_ROWS_FORCE_COLLECTIVES=1 -- every "
                          "collective of the step is issued through RCCL instead of being short-circuited (1-GPU boxes only)")
@@ -663,6 +666,10 @@ def main():
     one_dev = os.environ.get("MKB_BENCH_ONE_DEVICE", "0") == "1"
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
+    if args.dirty_memory > 0:
+        blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device=f"cuda:{dev_index}") for _ in range(max(1, int(args.dirty_memory)))]
+        torch.cuda.synchronize()
+        del blocks
     device = torch.device("cuda", dev_index)
     dist = None
     if world == 1 and args.rccl_world1:
