@@ -1,0 +1,71 @@
+"""-m gpu: random shapes through both routes.  For each seed: a model family, hidden size, batch size and negative count are
+drawn (odd sizes, sizes just above / below the kernels' tile edges included), the step's scores, loss and BOTH dense gradients
+are computed by the pooled route (shared-pool kernels: tile / single-pass / matrix-core forms, whichever the shape selects) and
+by the general route (arbitrary-candidate kernels + autograd), and compared on every element with tolerances relative to the
+reference's scale.  The row clamp of the 128-row GEMM tile (rounds 3-4) was a tile-edge bug of exactly the kind a fixed list of
+shapes does not meet."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import test_gpu_pool as T  # noqa: E402  (tests/ is on sys.path: conftest.py)
+
+EDGES = [1, 2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025]
+
+
+def _draw(seed):
+    rs = np.random.RandomState(1000 + seed)
+    name = T.MODELS[seed % len(T.MODELS)]
+
+    def pick(lo, hi):
+        if rs.rand() < 0.5:
+            c = [e for e in EDGES if lo <= e <= hi]
+            return int(c[rs.randint(len(c))])
+        return int(rs.randint(lo, hi + 1))
+
+    hidden = pick(2, 1100)
+    B = pick(1, 1300)
+    K = pick(1, 256)
+    return name, hidden, B, K
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MKB_FUZZ_SEEDS", "40"))))  # (MKB_FUZZ_SEEDS=400: the long hunt)
+def test_random_shape_pooled_equals_general(seed):
+    import mkb_amd.models.base as mb
+    from mkb_amd import losses
+    from mkb_amd.fused import pooled_supported
+
+    name, hidden, B, K = _draw(seed)
+    ds, m, tb, ns, train = T._setup("Fb15k237", name, hidden, B, K, gamma=9.0, seed=seed)
+    if not pooled_supported(m, B, K):
+        pytest.skip(f"{name} hidden {hidden} B {B} K {K}: not a pooled shape")
+    idx = torch.as_tensor(np.random.RandomState(seed).randint(len(train), size=B))
+    s = train[idx].cuda()
+    w = (torch.rand(B, generator=torch.Generator().manual_seed(seed)) + 0.1).cuda()
+    mode = "head-batch" if seed % 2 == 0 else "tail-batch"
+    neg = ns.generate(s, mode)
+    plain = neg.clone()
+    got = {}
+    for tag, n in (("pooled", neg), ("general", plain)):
+        m.zero_grad(set_to_none=True)
+        mb.AUTO_POOL = tag == "pooled"
+        try:
+            sc = m(s, n, mode)
+        finally:
+            mb.AUTO_POOL = True
+        err = losses.Adversarial(alpha=1.0)(m(s), sc, w)
+        err.backward()
+        got[tag] = (sc.detach().cpu().numpy(), err.item(), m.entity_embedding.grad.cpu().numpy().copy(),
+                    m.relation_embedding.grad.cpu().numpy().copy())
+    what = f"{name} hidden {hidden} B {B} K {K} {mode}"
+    sscale = max(np.abs(got["general"][0]).max(), 1e-6)
+    np.testing.assert_allclose(got["pooled"][0], got["general"][0], rtol=0, atol=2e-5 * max(sscale, 1.0), err_msg=what)
+    assert abs(got["pooled"][1] - got["general"][1]) <= 2e-6 * max(1.0, abs(got["general"][1])), what
+    for k in (2, 3):
+        scale = np.abs(got["general"][k]).max()
+        np.testing.assert_allclose(got["pooled"][k], got["general"][k], rtol=0, atol=2e-5 * max(scale, 1e-30), err_msg=what)
+    ns.check()
