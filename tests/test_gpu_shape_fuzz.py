@@ -1,7 +1,7 @@
 """-m gpu: random shapes through both routes.  For each seed: a model family, hidden size, batch size and negative count are
 drawn (odd sizes, sizes just above / below the kernels' tile edges included), the step's scores, loss and BOTH dense gradients
-are computed by the pooled route (shared-pool kernels: tile / single-pass / matrix-core forms, whichever the shape selects) and
-by the general route (arbitrary-candidate kernels + autograd), and compared on every element with tolerances relative to the
+are computed by the pooled route (shared-pool kernels: tile / single-pass / matrix-core forms, whichever the shape selects), by the fused
+step (one library call with the row kernels and the loss rows folded in) and by the general route (arbitrary-candidate kernels + autograd), and compared on every element with tolerances relative to the
 reference's scale.  The row clamp of the 128-row GEMM tile (rounds 3-4) was a tile-edge bug of exactly the kind a fixed list of
 shapes does not meet."""
 import os
@@ -61,11 +61,21 @@ def test_random_shape_pooled_equals_general(seed):
         err.backward()
         got[tag] = (sc.detach().cpu().numpy(), err.item(), m.entity_embedding.grad.cpu().numpy().copy(),
                     m.relation_embedding.grad.cpu().numpy().copy())
+    # ... and the fused step (one library call: row kernels + pooled forward + loss rows + single-pass / matrix backward)
+    from mkb_amd.fused import FusedTrainStep
+
+    m.zero_grad(set_to_none=True)
+    step = FusedTrainStep(m, alpha=1.0)
+    loss = step(s, w, neg, mode)
+    got["fused"] = (step.negative_score.cpu().numpy(), loss.item(), m.entity_embedding.grad.cpu().numpy().copy(),
+                    m.relation_embedding.grad.cpu().numpy().copy())
     what = f"{name} hidden {hidden} B {B} K {K} {mode}"
     sscale = max(np.abs(got["general"][0]).max(), 1e-6)
-    np.testing.assert_allclose(got["pooled"][0], got["general"][0], rtol=0, atol=2e-5 * max(sscale, 1.0), err_msg=what)
-    assert abs(got["pooled"][1] - got["general"][1]) <= 2e-6 * max(1.0, abs(got["general"][1])), what
-    for k in (2, 3):
-        scale = np.abs(got["general"][k]).max()
-        np.testing.assert_allclose(got["pooled"][k], got["general"][k], rtol=0, atol=2e-5 * max(scale, 1e-30), err_msg=what)
+    for route in ("pooled", "fused"):
+        tag = f"{what} [{route}]"
+        np.testing.assert_allclose(got[route][0], got["general"][0], rtol=0, atol=2e-5 * max(sscale, 1.0), err_msg=tag)
+        assert abs(got[route][1] - got["general"][1]) <= 2e-6 * max(1.0, abs(got["general"][1])), tag
+        for k in (2, 3):
+            scale = np.abs(got["general"][k]).max()
+            np.testing.assert_allclose(got[route][k], got["general"][k], rtol=0, atol=2e-5 * max(scale, 1e-30), err_msg=tag)
     ns.check()
