@@ -79,3 +79,35 @@ def test_random_shape_pooled_equals_general(seed):
             scale = np.abs(got["general"][k]).max()
             np.testing.assert_allclose(got[route][k], got["general"][k], rtol=0, atol=2e-5 * max(scale, 1e-30), err_msg=tag)
     ns.check()
+
+
+_N_RANK = max(1, int(os.environ["MKB_FUZZ_SEEDS"]) // 4) if "MKB_FUZZ_SEEDS" in os.environ else 10  # (each case walks 14,541 candidates per query on the host)
+
+
+@pytest.mark.parametrize("seed", range(_N_RANK))
+def test_random_shape_device_ranking_equals_reference_route(seed):
+    """The filtered ranking (mkb_rank: tiled all-entity forward + on-device filter count) against the reference's route
+    (TestDataset rows + general forward + argsort) for a random model / hidden size / evaluation batch size on FB15k-237's
+    14,541 candidates.  Single ranks may swap where two candidates' scores are closer than the routes' summation noise, so the
+    means are compared closely rather than exactly (a mis-addressed tile moves hundreds of ranks per query)."""
+    from mkb_amd import datasets, evaluation, models
+
+    rs = np.random.RandomState(4000 + seed)
+    name = T.MODELS[seed % len(T.MODELS)]
+    hidden = int(rs.choice([e for e in EDGES if 2 <= e <= 600])) if rs.rand() < 0.5 else int(rs.randint(2, 601))
+    bs = int(rs.randint(1, 71))
+    ds = datasets.Fb15k237(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    torch.manual_seed(seed)
+    m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=9).cuda().eval()
+    ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=bs,
+                               device="cuda", num_workers=0)
+    lo = int(rs.randint(0, len(ds.test) - 40))
+    test = ds.test[lo: lo + 1 + int(rs.randint(1, 40))]
+    fast = ev.eval(model=m, dataset=test)
+    ev.force_reference_path = True
+    slow = ev.eval(model=m, dataset=test)
+    what = f"{name} hidden {hidden} eval batch {bs} triples {len(test)}: {fast} vs {slow}"
+    assert abs(fast["MR"] - slow["MR"]) <= 0.002 * slow["MR"] + 0.5, what
+    assert abs(fast["MRR"] - slow["MRR"]) <= 2e-3, what
+    for k in ("HITS@1", "HITS@3", "HITS@10"):
+        assert abs(fast[k] - slow[k]) <= 1.01 / (2 * len(test)) + 1e-9, what
