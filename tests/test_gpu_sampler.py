@@ -292,3 +292,56 @@ def test_rocrand_sampler_rides_the_fused_training_loop():
     np.testing.assert_allclose(l1, l2, rtol=0, atol=1e-6)
     assert torch.allclose(e1, e2, rtol=0, atol=1e-5)
     assert l1 != l3 and all(np.isfinite(l1))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKB_FUZZ_SEEDS", "12"))))
+def test_random_graph_sampler_vs_c_oracle(liboracle, seed):
+    """Random graphs (entity count, relation count, density and hub skew drawn per seed), random K and B: the device sampler
+    must equal the plain-C restatement bit for bit -- pools, negatives and the generator state -- over six consecutive batches.
+    Dense little graphs drive the table / sort / loop branches of numpy's in1d semantics and big true sets; sparse big ones the
+    Bloom / bitmap probes; rows whose true set covers the whole pool are dropped from the batch (the reference hangs on them)."""
+    import ctypes
+
+    from mkb_amd import sampling
+    from mkb_amd.sampling.negative_sampling import _filter_csr
+
+    rs = np.random.RandomState(9000 + seed)
+    N = int(rs.choice([3, 17, 135, 1000, 14541, 60000]))
+    R = int(rs.choice([1, 2, 11, 237]))
+    T_ = int(min(200000, max(20, N * rs.choice([1, 4, 20]))))
+    if rs.rand() < 0.5:  # hub-heavy: Zipf-like entity draws
+        pe = 1.0 / np.arange(1, N + 1); pe /= pe.sum()
+        h, t = rs.choice(N, size=T_, p=pe), rs.choice(N, size=T_, p=pe)
+    else:
+        h, t = rs.randint(N, size=T_), rs.randint(N, size=T_)
+    train_np = np.unique(np.stack([h, rs.randint(R, size=T_), t], 1).astype(np.int64), axis=0)
+    K = int(rs.choice([1, 2, 7, 16, 64, 128, 256, 300, 512]))
+    B = int(rs.choice([1, 5, 64, 257, 1024]))
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    triples = [tuple(int(x) for x in row) for row in train_np]
+    ns = sampling.NegativeSampling(size=K, train_triples=triples, entities=ents, relations=rels, seed=seed)
+    (hk, ho, hv, _), (tk, to, tv, _) = _filter_csr(triples, N, R)
+    st = ctypes.create_string_buffer(4 * 624 + 4)
+    liboracle.orc_mt_seed(st, ctypes.c_uint32(seed))
+    liboracle.orc_generate.restype = ctypes.c_int
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    train = torch.as_tensor(train_np).cuda()
+    for c in range(6):
+        head = c % 2 == 0
+        idx = rs.randint(len(train_np), size=B)
+        smp = np.ascontiguousarray(train_np[idx])
+        want = np.zeros((B, K), dtype=np.int64)
+        pool = np.zeros(2 * K, dtype=np.int64)
+        k, o, v, stride = (hk, ho, hv, N) if head else (tk, to, tv, R)
+        rc = liboracle.orc_generate(st, ctypes.c_int64(N), ctypes.c_int64(K), p(smp), ctypes.c_int64(B), ctypes.c_int(head),
+                                    p(k), ctypes.c_int64(len(k)), p(o), p(v), ctypes.c_int64(stride), p(want), p(pool))
+        got = ns.generate(train[torch.as_tensor(idx).cuda()], "head-batch" if head else "tail-batch")
+        np.testing.assert_array_equal(got._mkb_pool.pool.cpu().numpy(), pool, err_msg=f"N {N} R {R} K {K} B {B} batch {c}")
+        if rc != 0:  # a row whose true set covers the whole pool: the oracle reports it, the device sampler flags it
+            with pytest.raises(RuntimeError, match="whole candidate pool"):
+                ns.check()
+            continue
+        np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"N {N} R {R} K {K} B {B} batch {c}")
+    key, pos = ns.get_state()
+    np.testing.assert_array_equal(key, np.frombuffer(st.raw[: 4 * 624], dtype=np.uint32))
+    assert pos == int(np.frombuffer(st.raw[4 * 624:], dtype=np.int32)[0])
