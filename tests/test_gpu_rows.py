@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-@pytest.mark.parametrize("b", [5, 1024, 1500])
+@pytest.mark.parametrize("b", [5, 1024, 1500, 2048, 2049, 3000])  # (2 b requests: merged through the LDS table up to 4096 of them)
 def test_route_groups_requests_by_owner_in_request_order(world, b):
     from mkb_amd.table_rows import HipRowOps
     from row_ops_torch import TorchRowOps
@@ -19,12 +19,12 @@ def test_route_groups_requests_by_owner_in_request_order(world, b):
                           torch.randint(100000, (b,), generator=g)], 1)
     sample[: b // 3, 0] = sample[0, 0]  # a hot entity: one owner gets far more than its share
     got = HipRowOps().route(sample.cuda(), world, row0=777, sample_layout=True)
-    ref = TorchRowOps().route(sample, world, row0=777, sample_layout=True)
+    ref = TorchRowOps().route(sample, world, row0=777, sample_layout=True, merge=2 * b <= 4096)
     for a, r in zip(got, ref):
         assert torch.equal(a.cpu(), r), (world, b)
     flat = torch.randint(5000, (2 * b + 1,), generator=g)
     got = HipRowOps().route(flat.cuda(), world)
-    ref = TorchRowOps().route(flat, world)
+    ref = TorchRowOps().route(flat, world, merge=2 * b + 1 <= 4096)
     assert got[3] is None and all(torch.equal(a.cpu(), r) for a, r in zip(got[:3], ref[:3]))
 
 
