@@ -548,7 +548,8 @@ def test_dim_sharded_training_equals_single_device(name, hidden, world, table):
 
 @pytest.mark.parametrize("name,hidden,world,size", [("RotatE", 24, 2, "small"), ("TransE", 33, 3, "small"), ("ComplEx", 16, 4, "small"),
                                                     ("pRotatE", 20, 2, "small"), ("RotatE", 40, 2, "big"), ("TransE", 32, 3, "big"),
-                                                    ("RotatE", 40, 1, "big")])  # world 1: no collective runs, rows move without copies
+                                                    ("RotatE", 40, 1, "big"),  # world 1: no collective runs, rows move without copies
+                                                    ("RotatE", 24, 2, "wide")])  # 2200 rows per rank: the routes' requests are NOT merged
 def test_row_sharded_table_training_equals_single_device(name, hidden, world, size):
     """BASELINE config 5's partitioning (mkb_amd.table_rows): entity rows, their gradient and their Adam state sharded by
     row over `world` processes (gloo, all on this one GPU), the fused HIP step running on the compact table of each rank.

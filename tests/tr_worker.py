@@ -20,7 +20,8 @@ def main():
     name, hidden, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     size = sys.argv[4] if len(sys.argv) > 4 else "small"
     yago = size == "yago"          # BASELINE config 5's table (123,182 entities) at its batch size: 1024 rows per rank
-    big = size == "big" or yago    # FB15k-237: shards of > 4096 rows step ROW-LAZILY, real step deferred
+    wide = size == "wide"          # FB15k-237 with 2200 rows per rank: 4400 row requests, more than the route kernel merges (4096)
+    big = size == "big" or yago or wide    # FB15k-237: shards of > 4096 rows step ROW-LAZILY, real step deferred
     # MKB_TR_BACKEND=nccl: the collectives go through RCCL (one rank per GPU; at world 1 together with
     # MKB_ROWS_FORCE_COLLECTIVES=1, which keeps the step from short-circuiting them: tests/test_gpu_rccl_world1.py)
     backend = os.environ.get("MKB_TR_BACKEND", "gloo")
@@ -33,7 +34,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     ds = (datasets.Yago310 if yago else datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
-    B = (1024 if yago else 64 if big else 24) * world
+    B = (1024 if yago else 2200 if wide else 64 if big else 24) * world
     adam_kw = dict(lazy_rows=True, defer_step=True) if big else {}
 
     def batches():
