@@ -244,7 +244,7 @@ __device__ __forceinline__ float2 replay_consts(const AdamRowArgs &A, int s) {
 // gradient.  A serial chain per element (2 transcendentals per step); a row's gap can be hundreds of steps (entities only
 // the random pool ever touches), so the chain is kept short: half a workgroup (512 lanes x float4) or a whole one
 // (1024 lanes x float2) per row.
-template <int EPL>
+template <int EPL, int UNROLL = kReplayUnroll>
 __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, RowChunk<EPL> &c) {
     f2 p[EPL / 2], m[EPL / 2], v[EPL / 2];
 #pragma unroll
@@ -265,27 +265,27 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
         ++s;
     }
     // Zero-gradient steps.  `from` / `to` are wave-uniform (scalar registers), so the per-step constants come through the
-    // scalar cache; they are fetched kReplayUnroll steps ahead of their use, and the steps of a group are written out side by
+    // scalar cache; they are fetched UNROLL steps ahead of their use, and the steps of a group are written out side by
     // side: per element the only serial links between steps are ONE multiply (v), ONE fma (m) and ONE add (p) -- the
     // sqrt / rcp chains of neighbouring steps overlap.  (Before: one vector load round trip + a 7-deep chain per step; the
     // launch lasted as long as the row with the longest gap -- WN18RR: ~900 pending steps.)
     const int last_tab = A.g ? to - 1 : to;  // the advance form's own step is recorded by this very launch: not in the table
-    if (s + kReplayUnroll - 1 <= last_tab) {
-        float2 nx[kReplayUnroll];
+    if (s + UNROLL - 1 <= last_tab) {
+        float2 nx[UNROLL];
 #pragma unroll
-        for (int u = 0; u < kReplayUnroll; ++u) nx[u] = A.consts[s + u];
+        for (int u = 0; u < UNROLL; ++u) nx[u] = A.consts[s + u];
         for (;;) {
-            float2 cs[kReplayUnroll];
+            float2 cs[UNROLL];
 #pragma unroll
-            for (int u = 0; u < kReplayUnroll; ++u) cs[u] = nx[u];
-            s += kReplayUnroll;
-            const bool more = s + kReplayUnroll - 1 <= last_tab;
+            for (int u = 0; u < UNROLL; ++u) cs[u] = nx[u];
+            s += UNROLL;
+            const bool more = s + UNROLL - 1 <= last_tab;
             if (more) {
 #pragma unroll
-                for (int u = 0; u < kReplayUnroll; ++u) nx[u] = A.consts[s + u];
+                for (int u = 0; u < UNROLL; ++u) nx[u] = A.consts[s + u];
             }
 #pragma unroll
-            for (int u = 0; u < kReplayUnroll; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 const float inv = __builtin_amdgcn_rcpf(cs[u].y);
 #pragma unroll
                 for (int e = 0; e < EPL / 2; ++e) adam_pair_zero_grad(p[e], m[e], v[e], A.w1, A.b2, cs[u].x, inv, A.eps);
@@ -385,6 +385,40 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
     if (row < 0) { valid = false; row = 0; }  // a negative id = "not a row of this table" (an entry another rank owns): skipped
     if (A.vec4) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
     else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
+}
+
+// A flush (every row of the table, no id list, no riders) is a stream over the whole table: p, m, v of every row with pending
+// steps in and out (FB15k-237 / hidden 1000: 700 MB).  Through the catch-up kernel above -- 107 VGPRs for its four steps replayed
+// side by side, one 1024-lane workgroup per CU -- it runs at 3.4 TB/s (0.22 ms: 11 us per step of a 20-step run).  Here: one
+// 256-lane workgroup per row, the steps replayed ONE at a time (same functions, same order of operations per element: the same bits),
+// few registers, eight waves per SIMD to keep HBM busy.
+__global__ __launch_bounds__(256) void adam_rows_flush_kernel(AdamRowArgs A) {
+    __shared__ int s_old;
+    const int64_t row = blockIdx.x;
+    if (A.g && A.step > 0 && blockIdx.x == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
+    if (row >= A.n_rows_listed) {  // the dense rider of a deferred step (the small relation table): the last blocks
+        const int64_t nb = (int64_t)gridDim.x - A.n_rows_listed;
+        adam_dense_range(A.dp, A.dg, A.dm, A.dv, A.dn, (row - A.n_rows_listed) * 256 + threadIdx.x, nb * 256, A.w1, A.b2, A.w2,
+                         A.d_neg_step, A.d_sqrt_bc2, A.eps, 1);
+        return;
+    }
+    if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
+    __syncthreads();
+    const int old = __builtin_amdgcn_readfirstlane(s_old);
+    if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
+    if (A.vec4) {
+        for (int64_t k = (int64_t)threadIdx.x * 4; k < A.D; k += 1024) {
+            RowChunk<4> c;
+            replay_load<4>(A, row, k, c);
+            replay_finish<4, 1>(A, row, k, old, A.step, c);
+        }
+    } else {
+        for (int64_t k = (int64_t)threadIdx.x * 2; k < A.D; k += 512) {
+            RowChunk<2> c;
+            replay_load<2>(A, row, k, c);
+            replay_finish<2, 1>(A, row, k, old, A.step, c);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
@@ -523,6 +557,14 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
     set_row_blocks(A, n, (ids || own_ids) ? n_rows : 0);  // (a flush walks the whole table anyway)
     n = A.n_ids;
     int64_t extra = 0;
+    static const bool no_flush_kernel = getenv("MKB_ADAM_NO_FLUSH_KERNEL") != nullptr;  // A/B switch
+    if (!ids && !own_ids && A.n_rows_listed > 0 && A.n_rows_listed == A.n_batch_rows && !no_flush_kernel) {  // the whole table
+        if (int rc = attach_rider(A, rider, lr, beta1, beta2, 256, &extra)) return rc;
+        ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
+        hipLaunchKernelGGL(adam_rows_flush_kernel, dim3((unsigned)(A.n_rows_listed + extra)), dim3(256), 0, (hipStream_t)stream, A);
+        MKB_LAUNCH_CHECK();
+        return MKB_OK;
+    }
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
     if (n + extra == 0) return MKB_OK;
     size_t lds = 0;
