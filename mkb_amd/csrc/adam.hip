@@ -161,8 +161,11 @@ __device__ __forceinline__ void adam_zero_grad_step(float &p, float &m, float &v
 }
 
 // workgroup size of the catch-up / advance kernel (the sampler's filter and draw blocks that ride it are sized by it too)
+// 512 lanes: one 2000-float row per workgroup, two workgroups per CU (107 VGPRs): their phases -- ownership exchange, loads, replay,
+// stores -- interleave.  Round 4, same box, 1024 -> 512 lanes: headline step 0.2273 -> 0.2242 ms, WN18RR 0.1302 -> 0.1262, YAGO3-10
+// 0.1933 -> 0.1862 (256 lanes: better still for YAGO3-10's long replays, worse at the headline; tools/_kb_catch.sh)
 #ifndef MKB_CATCH_THREADS
-#define MKB_CATCH_THREADS 1024
+#define MKB_CATCH_THREADS 512
 #endif
 constexpr int kCatchThreads = MKB_CATCH_THREADS;
 #ifndef MKB_REPLAY_UNROLL
@@ -512,7 +515,7 @@ static void set_row_blocks(AdamRowArgs &A, int64_t rows, int64_t n_table = 0) {
     }
     bool vec4 = (A.D & 3) == 0 && (((uintptr_t)A.p | (uintptr_t)A.m | (uintptr_t)A.v | (uintptr_t)A.g) & 15) == 0;
     A.vec4 = vec4 ? 1 : 0;
-    // as many rows per 1024-lane workgroup as fit with one chunk per lane (whole waves per row): 2000-float rows 2,
+    // as many rows per workgroup (kCatchThreads lanes) as fit with one chunk per lane (whole waves per row): at 1024 lanes 2000-float rows 2,
     // 1000-float rows 4, the 250-float rows of an 8-way dimension shard 8 -- short rows used to idle most of the lanes
     const int64_t per_lane = vec4 ? 4 : 2;
     int64_t lanes = ((A.D + per_lane - 1) / per_lane + 63) / 64 * 64;
@@ -588,10 +591,10 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
                            beta1, beta2, eps)) return rc;
     size_t lds = 0;
     ProfScope ps(MKB_PROF_SAMPLER, st);
-    if (int rc = sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st))
+    if (int rc = sampler_ride(sampler, sample, B, mode, neg, pool, pos, cnt, touched, &A.filt, &A.draw, &A.seg_pool, &lds, st, kCatchThreads))
         return rc;
     A.first_row_block = 1;
-    A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= 16 rows per 1024-lane workgroup
+    A.n_filter = (int32_t)((B + A.filt.rows_per_wg - 1) / A.filt.rows_per_wg);  // one wave per row, <= kCatchThreads / 64 rows per workgroup
     A.seg_sample = sample; A.seg_P = A.filt.P; A.seg_B = (int32_t)B;
     if (own_world > 0) {
         // shard of a row-sharded table: the rows to visit are the pool ids this rank owns (the sampler's pool buffer holds

@@ -259,15 +259,15 @@ static mkb::FilterArgs filter_args(mkb_sampler *s, const int64_t *sample, int64_
 
 int mkb::sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode, int64_t *neg, int64_t *pool, int32_t *pos,
                       uint16_t *cnt, int64_t *touched, FilterArgs *F, DrawArgs *D, const int64_t **pool_ids,
-                      size_t *lds_bytes, hipStream_t st) {
+                      size_t *lds_bytes, hipStream_t st, int carrier_lanes) {
     MKB_REQUIRE(s && sample && neg, "null pointer");
     MKB_REQUIRE(mode == MKB_MODE_HEAD || mode == MKB_MODE_TAIL, "generate needs head-batch or tail-batch");
     MKB_REQUIRE(B > 0 && B <= INT32_MAX, "bad B");
     MKB_REQUIRE(s->P() <= 1024, "riding the optimizer launch supports size <= 512");
     bool was_ahead = false;
     if (int rc = take_pool(s, pool, st, &was_ahead)) return rc;
-    // 1024-lane carrier blocks: one wave per row, as many rows per block as fit the carrier's 96 KB dynamic-LDS opt-in
-    int rw = 16;
+    // the carrier's blocks: one wave per row, as many rows per block as fit the carrier's 96 KB dynamic-LDS opt-in
+    int rw = carrier_lanes / 64;
     while (rw > 1 && filter_lds_bytes(s->P(), s->P2(), rw) > (size_t)96 * 1024) --rw;
     *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, rw);
     *pool_ids = F->pool;

@@ -402,5 +402,5 @@ bool sampler_draw_ahead(mkb_sampler *s, DrawArgs *D, size_t *lds_bytes);
 // buffer.  *pool_ids = this batch's pool on the device (valid until the generate after next).
 int sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode, int64_t *neg, int64_t *pool, int32_t *pos,
                  uint16_t *cnt, int64_t *touched, FilterArgs *F, DrawArgs *D, const int64_t **pool_ids, size_t *lds_bytes,
-                 hipStream_t st);
+                 hipStream_t st, int carrier_lanes = 1024);  // carrier_lanes: workgroup size of the launch that carries the rows
 }
