@@ -84,7 +84,7 @@ def test_random_shape_fast_loop_equals_the_plain_loop(seed):
     plain = [p.detach().clone() for p in params] + [torch.stack(plain_losses)]
 
     what = f"{name} hidden {hidden} B {B} K {K}"
-    np.testing.assert_allclose(fast[-1].cpu().numpy(), plain[-1].cpu().numpy(), rtol=0, atol=5e-6, err_msg=what)
+    np.testing.assert_allclose(fast[-1].cpu().numpy(), plain[-1].cpu().numpy(), rtol=2e-6, atol=5e-6, err_msg=what)  # (losses up to ~100: a few fp32 ulp)
     # an element moves <= lr per step.  Gradients are sums in different orders (and fp32 atomics): where a sum cancels to exactly
     # 0 in one order and to a rounding residue in the other, Adam turns the residue into a full step (tests/test_gpu_defer.py) --
     # so: nearly every element agrees to a small fraction of one step, none is off by more than the steps taken
