@@ -428,7 +428,10 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         run_step(ctx, i)
     barrier()
     prof_kind = args.profile_kernel if profile else "none"
+    first = warmup  # index of the first timed batch: batches are consumed in order (the row-sharded step plans the NEXT batch's
+    #                 routes while it runs: a gap in the sequence is an error there, not a harmless skip)
     if prof_kind == "auto":  # pick the dominant kernel class on a short probe
+        first = warmup + 8
         for k in kinds:
             _hip.profile_enable(k, True)
         for i in range(8):
@@ -450,7 +453,7 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
     barrier()
     t0 = time.perf_counter()
     for i in range(steps):
-        loss = run_step(ctx, warmup + 8 + i)
+        loss = run_step(ctx, first + i)
     ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
     t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
     barrier()
