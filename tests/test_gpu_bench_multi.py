@@ -52,6 +52,21 @@ def test_bench_default_partitioning_is_table_rows_and_reports_the_others():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["parallelism"].startswith("table-rows2") and "partitioning_failures" not in d
     assert set(d["other_partitionings"]) == {"dims", "rows"} and all(v["value"] > 0 for v in d["other_partitionings"].values())
+    assert "extras_error" not in d, d["extras_error"]
+    # ... and the other way round: another partitioning as the line's value, the row-sharded step among the extras (measured
+    # without the kernel-class probe: its timed batches must follow the warm-up batches without a gap -- the step plans the next
+    # batch's routes, a skipped batch is an error there; round 4 found the extras ending in exactly that error)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--config", "wn18rr-rotate", "--parallelism", "dims"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["parallelism"].startswith("dims2") and "extras_error" not in d, d.get("extras_error")
+    assert set(d["other_partitionings"]) == {"table-rows", "rows"} and all(v["value"] > 0 for v in d["other_partitionings"].values())
 
 
 def test_bench_table_rows_code_path_on_one_rank():
