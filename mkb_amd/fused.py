@@ -26,11 +26,35 @@ def _workspace(model, B, K, slot=0):
     ws = _workspaces.get(key)
     if ws is None:
         n = _hip.lib().mkb_pool_step_workspace_bytes(model._tables(), B, K)
-        ws = torch.empty(n + 256, dtype=torch.uint8, device=dev)
-        off = (-ws.data_ptr()) % 256
-        ws = ws[off: off + n]
+        guard = _GUARD_BYTES if _guard_on() else 0
+        buf = torch.empty(n + 256 + guard, dtype=torch.uint8, device=dev)
+        off = (-buf.data_ptr()) % 256
+        ws = buf[off: off + n]
+        if guard:  # (debug: a pattern behind the workspace that no kernel may touch; check_workspace_guards() looks at it)
+            buf[off + n:].fill_(_GUARD_VALUE)
+            _guards[key] = buf[off + n:]
         _workspaces[key] = ws
     return ws
+
+
+_GUARD_BYTES, _GUARD_VALUE = 1 << 16, 0xA5
+_guards = {}
+
+
+def _guard_on():
+    import os
+
+    return os.environ.get("MKB_WS_GUARD", "0") == "1"
+
+
+def check_workspace_guards():
+    """MKB_WS_GUARD=1 (tests): every cached workspace is followed by 64 KB of a byte pattern; raise if a kernel wrote there
+    (the library takes the workspace as a bare pointer: nothing else would notice an overrun that stays inside the allocator's
+    block).  Synchronises."""
+    for key, g in _guards.items():
+        if not bool((g == _GUARD_VALUE).all().item()):
+            bad = int((g != _GUARD_VALUE).nonzero()[0].item())
+            raise RuntimeError(f"pooled-kernel workspace overrun: byte {bad} behind the workspace of {key[1:]} was overwritten")
 
 
 def pooled_supported(model, B, K):

@@ -54,3 +54,16 @@ def _dirty_device_memory(request):
             torch.cuda.synchronize()
             del blocks
     yield
+
+
+@pytest.fixture(autouse=True)
+def _workspace_guards(request):
+    """MKB_WS_GUARD=1: after every -m gpu test, the pattern behind each cached pooled-kernel workspace must be intact
+    (mkb_amd.fused.check_workspace_guards)."""
+    yield
+    import os
+
+    if os.environ.get("MKB_WS_GUARD", "0") == "1" and request.node.get_closest_marker("gpu") is not None:
+        from mkb_amd import fused
+
+        fused.check_workspace_guards()

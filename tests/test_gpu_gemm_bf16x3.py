@@ -150,3 +150,23 @@ def test_switching_routes_in_one_process_on_dirty_device_memory():
         assert abs(got[0] - ref[0]) <= 1e-6
         np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=3e-6 * np.abs(ref[1]).max())
         np.testing.assert_allclose(got[2], ref[2], rtol=0, atol=3e-6 * np.abs(ref[2]).max())
+
+
+def test_workspace_guard_notices_a_write_behind_the_workspace(monkeypatch):
+    """MKB_WS_GUARD=1 puts 64 KB of a byte pattern behind every cached pooled-kernel workspace (the library takes the workspace
+    as a bare pointer); the conftest fixture checks it after every GPU test.  Here: the check itself."""
+    from mkb_amd import datasets, fused, models
+
+    monkeypatch.setenv("MKB_WS_GUARD", "1")
+    ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
+    m = models.DistMult(hidden_dim=44, entities=ds.entities, relations=ds.relations, gamma=6).cuda()
+    ws = fused._workspace(m, 96, 24)  # (a shape no other test uses: a fresh cache entry, with its guard)
+    fused.check_workspace_guards()
+    key = [k for k in fused._guards if k[5:7] == (96, 24) and k[2] == m.entity_dim][0]
+    guard = fused._guards[key]
+    assert guard.data_ptr() == ws.data_ptr() + ws.numel()
+    guard[5] = 0
+    with pytest.raises(RuntimeError, match="workspace overrun"):
+        fused.check_workspace_guards()
+    guard[5] = fused._GUARD_VALUE
+    fused.check_workspace_guards()
