@@ -125,8 +125,9 @@ def run_step(ctx, i):
     if ctx.get("trows"):  # row-sharded entity table: this rank's rows of the global batch, ONE shared pool (replicated RNG)
         lo = ((i * world + rank) * Bl) % (n - Bl)
         sample, weight = ctx["train"][lo: lo + Bl], ctx["weights"][lo: lo + Bl]
-        nlo = (((i + 1) * world + rank) * Bl) % (n - Bl)  # the next batch: its routing is prepared while this step runs
-        loss = ctx["step"].sampled(sample, weight, ctx["sampler"], mode, next_sample=ctx["train"][nlo: nlo + Bl])
+        # the next two batches: their routing (route kernel + id exchange, side stream) is prepared while this step runs
+        ahead = [ctx["train"][nlo: nlo + Bl] for nlo in ((((i + d) * world + rank) * Bl) % (n - Bl) for d in (1, 2))]
+        loss = ctx["step"].sampled(sample, weight, ctx["sampler"], mode, next_sample=ahead[: ctx.get("lookahead", 2)])
         ctx["opt"].step()
         ctx["opt"].zero_grad()
         return loss
@@ -742,10 +743,21 @@ def main():
         if ctx["trows"]:
             from mkb_amd.table_rows import _collectives_run, _Route
 
+            comm = getattr(ctx["step"], "_comm", None)
             out["table_rows"] = {"collectives_issued": bool(_collectives_run(world)), "backend": dist.get_backend() if dist is not None and dist.is_initialized() else None,
-                                 "host_waits_that_blocked": _Route.host_waits, "steps_counted": args.warmup + 8 + args.steps,
-                                 "note": "host_waits_that_blocked = steps whose split sizes (read back one batch ahead on a side stream) "
-                                         "were not there yet when the step needed them"}
+                                 "issued_by": "libmkb_hip.so (own RCCL communicators: mkb_rows_comm_*)" if comm else "torch.distributed",
+                                 "steps_counted": args.warmup + 8 + args.steps}
+            if comm:
+                st = comm.stats()
+                out["table_rows"].update(st, host_waits_that_blocked=st["waited_with_idle_stream"],
+                                         note="split sizes reach the host through a mailbox the plan's last kernel writes (planned two batches "
+                                              "ahead on a side stream); takes_that_waited = the host asked before the plan had executed (it "
+                                              "ran ahead of the device); host_waits_that_blocked = those of them that found the step's "
+                                              "stream EMPTY, i.e. the device without work")
+            else:
+                out["table_rows"].update(host_waits_that_blocked=_Route.host_waits,
+                                         note="host_waits_that_blocked = steps whose split sizes (read back one batch ahead on a side "
+                                              "stream) were not there yet when the step needed them")
 
     # ---- N > 1: the other partitionings and BASELINE configs[4] in the same run (fewer steps; same barrier + max-over-ranks
     # timing).  A watchdog prints the line without them if they hang: the headline number must not be lost to an extra.

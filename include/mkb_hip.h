@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MKB_ABI_VERSION 4
+#define MKB_ABI_VERSION 5
 
 typedef enum {
     MKB_OK = 0,
@@ -294,6 +294,44 @@ int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp
                                            float beta1, float beta2, float eps, const mkb_adam_dense_t *rider,
                                            mkb_sampler_t *sampler, const int64_t *sample, int64_t B, int mode, int64_t *neg,
                                            int64_t *pool, int32_t *pos, uint16_t *cnt, int64_t *touched, void *stream);
+
+/* ---- the row-sharded step's collectives, issued by the library (no reference counterpart: mkb is single-process) ------------
+ * mkb_amd/table_rows.py used to issue the step's six collectives through torch.distributed and to read the all-to-alls' split
+ * sizes back with an event wait: measured host-bound (0.43 ms / step against 0.19 ms of kernels, round 4).  With these entry
+ * points the library holds its own RCCL communicators (bound at run time: mkb_rows_comm_available() is 0 on a box without
+ * librccl, everything else still loads) and a step's communication is plan (ahead, side stream) + take + 2 x exchange.
+ *
+ * mkb_rows_comm_unique_id: rank 0 fills id_host [MKB_ROWS_COMM_ID_BYTES]; the caller hands the blob to every rank by whatever
+ *   means it has (mkb_amd: one torch.distributed broadcast at set-up).
+ * mkb_rows_comm_create: collective over the `world` ranks (each on its own current device).  max_requests = the largest 2 x b
+ *   (positive-row requests of one rank's batch) any rank will ever plan: the id lists travel in fixed blocks of that capacity.
+ * mkb_rows_comm_plan (slot in [0, 4): the caller's ring of plans in flight): on side_stream (after the work queued on
+ *   after_stream so far, when given) -- mkb_rows_route on sample [b, 3] (send_ids [2b], slot_of [2b], counts [world],
+ *   compact [b, 3]: as there), then the id exchange with in-band counts, then `want` [want_cap >= world's total requests to this
+ *   owner; 2 b x world always suffices] = the shard indices the ranks ask this owner for, requester after requester.  Nothing
+ *   returns to the host except through the mailbox below.  bad: as mkb_rows_route; bit 2 = a peer's block was malformed.
+ * mkb_rows_comm_take: the split sizes of that plan -- sent_host [world] rows this rank asks each owner for, wanted_host [world]
+ *   rows each rank asks this owner for -- read from a host-coherent mailbox the plan's last kernel wrote (no HIP call; spins
+ *   only when the plan has not executed yet), and `stream` is made to wait for the plan.
+ * mkb_rows_comm_exchange: ONE RCCL group on `stream`: all-reduce (sum, in place) of reduce [reduce_n] floats (0 = none) and the
+ *   all-to-all of rows of D floats: send_rows_host[p] rows to rank p from `send` (consecutive), recv_rows_host[p] rows from
+ *   rank p into `recv` (null count vectors = no all-to-all).  Forward: owners send `wanted`, users receive `sent`; the
+ *   gradients' way back swaps the two.
+ * mkb_rows_comm_stats: plans made, takes that found their plan not executed yet, and how many of those found `stream` idle
+ *   (only those are bubbles on the device: the others mean the host ran ahead of it). */
+#define MKB_ROWS_COMM_ID_BYTES 256
+typedef struct mkb_rows_comm mkb_rows_comm_t;
+int mkb_rows_comm_available(void);
+int mkb_rows_comm_unique_id(uint8_t *id_host);
+int mkb_rows_comm_create(const uint8_t *id_host, int rank, int world, int64_t max_requests, mkb_rows_comm_t **out);
+void mkb_rows_comm_destroy(mkb_rows_comm_t *comm);
+int mkb_rows_comm_plan(mkb_rows_comm_t *comm, int slot, const int64_t *sample, int64_t b, int64_t row0, int64_t *send_ids,
+                       int32_t *slot_of, int64_t *counts, int64_t *compact, int64_t *want, int64_t want_cap, int32_t *bad,
+                       void *after_stream, void *side_stream);
+int mkb_rows_comm_take(mkb_rows_comm_t *comm, int slot, int64_t *sent_host, int64_t *wanted_host, void *stream);
+int mkb_rows_comm_exchange(mkb_rows_comm_t *comm, float *reduce, int64_t reduce_n, const float *send,
+                           const int64_t *send_rows_host, float *recv, const int64_t *recv_rows_host, int64_t D, void *stream);
+int mkb_rows_comm_stats(mkb_rows_comm_t *comm, int64_t *plans, int64_t *takes_that_waited, int64_t *waited_with_idle_stream);
 
 /* ---- filtered ranking --------------------------------------------------------------------------------
  * == evaluation.Evaluation.compute_score for head-/tail-batch (evaluation/evaluation.py:217-279) with the

@@ -14,7 +14,7 @@ import os
 
 # MKB_HIP_LIB selects an experimental build of the same ABI (tools/kbench.py); default = the in-tree product library
 _LIB_PATH = pathlib.Path(os.environ.get("MKB_HIP_LIB") or (pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"))
-ABI_VERSION = 4  # == MKB_ABI_VERSION of include/mkb_hip.h (bumped whenever a symbol or a signature changes)
+ABI_VERSION = 5  # == MKB_ABI_VERSION of include/mkb_hip.h (bumped whenever a symbol or a signature changes)
 
 MODEL_IDS = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}
 MODE_DEFAULT, MODE_HEAD, MODE_TAIL = 0, 1, 2
@@ -107,6 +107,15 @@ _SIGNATURES = {
                                 c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_scatter_add": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_void_p, c_int64,
                                      c_void_p, c_void_p, c_void_p]),
+    "mkb_rows_comm_available": (c_int, []),
+    "mkb_rows_comm_unique_id": (c_int, [c_void_p]),
+    "mkb_rows_comm_create": (c_int, [c_void_p, c_int, c_int, c_int64, POINTER(c_void_p)]),
+    "mkb_rows_comm_destroy": (None, [c_void_p]),
+    "mkb_rows_comm_plan": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_void_p, c_void_p, c_void_p]),
+    "mkb_rows_comm_take": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mkb_rows_comm_exchange": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mkb_rows_comm_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "mkb_adam_rows_advance_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                               c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int64, c_float, c_float,
                                               c_float, c_float, POINTER(AdamDense), c_void_p, c_void_p]),

@@ -9,10 +9,28 @@ out of the model: nothing here survives or travels with a parameter.
 import torch
 from torch.utils.weak import WeakIdKeyDictionary
 
-__all__ = ["attach", "detach", "mark_touched", "owner", "take_touched", "touched"]
+__all__ = ["attach", "autograd_wrote", "clear_autograd_wrote", "detach", "mark_touched", "owner", "take_touched", "touched"]
 
 _owner = WeakIdKeyDictionary()    # parameter -> optimizer that defers its zero-gradient row steps
 _touched = WeakIdKeyDictionary()  # parameter -> int64 ids of the rows written since the optimizer last stepped
+_hooks = WeakIdKeyDictionary()    # parameter -> handle of the post-accumulate hook below
+_wrote = WeakIdKeyDictionary()    # parameter -> True once AUTOGRAD has accumulated into .grad since the optimizer last stepped
+
+
+def _note_autograd_write(p):
+    _wrote[p] = True
+
+
+def autograd_wrote(p):
+    """True if torch's autograd has accumulated into ``p.grad`` since the optimizer last stepped / cleared it (any route:
+    ``model(sample, negatives, mode)`` + ``loss.backward()``, a regulariser on the table, ...).  The fused step bypasses autograd
+    and does not count.  A gradient row written that way is NOT all-zero, so the fused step's row kernels must accumulate into
+    it (``mkb_grads_t.rows_clear`` stays 0)."""
+    return bool(_wrote.get(p, False))
+
+
+def clear_autograd_wrote(p):
+    _wrote.pop(p, None)
 
 
 def owner(p):
@@ -21,11 +39,17 @@ def owner(p):
 
 def attach(p, optimizer):
     _owner[p] = optimizer
+    if p not in _hooks and hasattr(p, "register_post_accumulate_grad_hook"):
+        _hooks[p] = p.register_post_accumulate_grad_hook(_note_autograd_write)
 
 
 def detach(p):
     _owner.pop(p, None)
     _touched.pop(p, None)
+    _wrote.pop(p, None)
+    h = _hooks.pop(p, None)
+    if h is not None:
+        h.remove()
 
 
 def touched(p):
@@ -41,4 +65,5 @@ def mark_touched(p, ids, replace=False):
 
 
 def take_touched(p):
+    _wrote.pop(p, None)
     return _touched.pop(p, None)

@@ -350,6 +350,9 @@ constexpr int kBfPitch = 80;  // bytes between rows of a bf16 plane
 
 // two values -> one word per plane (element k in the low half, k + 1 in the high half): v_cvt_pk_bf16_f32 rounds to nearest and
 // packs in one instruction; x - hi and (x - hi) - mid are exact in fp32.  11 VALU operations per pair.
+// Non-finite operands: +-Inf (and |x| > ~3.39e38, which rounds to Inf in bf16) give hi = Inf, x - hi = NaN, i.e. a NaN product
+// where the fp32 kernel and the reference give +-Inf; NaN stays NaN.  Either way the table is beyond repair -- no guard is
+// spent on it in the staging loop (MKB_GEMM_BF16X3=0 selects the fp32-input instruction, which propagates Inf like the reference).
 __device__ __forceinline__ void split3_bf16_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -645,7 +648,8 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             // (its buffer loads address an operand with 32-bit byte offsets: every row it can touch must lie within 4 GB of the base)
             const int64_t a_span = (A_MK ? (int64_t)G.M * G.lda : (int64_t)G.K * G.lda) * 4;
             const int64_t b_rows = G.b_idx ? G.b_rows : (B_NK ? (int64_t)G.N : (int64_t)G.K);
-            const bool fits32 = a_span < ((int64_t)1 << 32) && b_rows > 0 && b_rows * G.ldb * 4 < ((int64_t)1 << 32);
+            // (offsets are added as SIGNED 32-bit integers in the staging: operands of 2 GB and more take the fp32 kernel)
+            const bool fits32 = a_span < ((int64_t)1 << 31) && b_rows > 0 && b_rows * G.ldb * 4 < ((int64_t)1 << 31);
             const bool bf16x3 = fits32 && (bx ? bx[0] == '1' : kGemmBf16x3Default);
             const size_t lds_bf = (size_t)3 * (128 + tn) * kBfPitch + (size_t)(((G.K + ks - 1) / ks + 31) / 32 * 32) * 4;
             auto launch128 = [&](auto epi_c, auto tn_c, const GemmArgs &GA) -> int {

@@ -302,7 +302,11 @@ extern "C" int mkb_rows_route(const int64_t *ids, int64_t n, int sample_layout, 
         A.merge_cap = cap;
         lds = (size_t)cap * 12;
         static LdsOptIn grant;
-        if (int rc = grant.ensure(reinterpret_cast<const void *>(&rows_route_kernel), lds)) return rc;
+        if (grant.ensure(reinterpret_cast<const void *>(&rows_route_kernel), lds) != MKB_OK) {
+            (void)hipGetLastError();  // a device that does not grant the table: route without merging (still correct, more rows travel)
+            A.merge_cap = 0;
+            lds = 0;
+        }
     }
     hipLaunchKernelGGL(rows_route_kernel, dim3(1), dim3(kRouteThreads), lds, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();

@@ -180,6 +180,7 @@ extern "C" int mkb_sampler_set_state(mkb_sampler_t *s, const uint32_t *key624_ho
 extern "C" int mkb_sampler_set_rng(mkb_sampler_t *s, int kind, uint64_t seed, uint64_t draws) {
     MKB_REQUIRE(s != nullptr && (kind == 0 || kind == 1), "bad sampler / rng kind");
     MKB_REQUIRE(!s->drawn_ahead || kind == s->rng_kind, "a pool drawn ahead is pending: switch generators before the first generate");
+    if (kind == 1) s->drawn_ahead = false;  // a pool drawn ahead from the old counter is discarded (as mkb_sampler_set_state does)
     s->rng_kind = kind; s->fast_seed = seed; s->fast_draw = draws;
     return MKB_OK;
 }

@@ -165,8 +165,9 @@ class FusedTrainStep:
             # Deferred real step: that launch consumed AND cleared the gradient row of every row it visited (= every entity row
             # this step writes), so unless an earlier backward of this same optimizer step has written since, those rows are
             # all-zero: the row kernels may store instead of read-modify-write (mkb_grads_t.rows_clear)
-            if (st.get("defer") and st["n"] >= 1 and _links.touched(ent) is None and st.get("g") is not None
-                    and st["g"].data_ptr() == ent.grad.data_ptr()):
+            # (autograd_wrote: an autograd backward of this same optimizer step has accumulated into .grad without marking rows)
+            if (st.get("defer") and st["n"] >= 1 and _links.touched(ent) is None and not _links.autograd_wrote(ent)
+                    and st.get("g") is not None and st["g"].data_ptr() == ent.grad.data_ptr()):
                 gr.rows_clear = 1
             _links.mark_touched(ent, ids)  # accumulates when several steps share one optimizer.step()
         with _hip.on_device(dev):

@@ -234,7 +234,10 @@ class Adam:
             g = p.grad
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
+            wrote = _links.autograd_wrote(p)
             touched = _links.take_touched(p) if _links.owner(p) is self else None
+            if wrote:  # autograd accumulated into .grad in this step as well: which rows is unknown -> the dense route below
+                touched = None
             with _hip.on_device(p.device):
                 if touched is not None:
                     done = st.get("caught_up")
@@ -283,6 +286,7 @@ class Adam:
         if any(st.get("defer") for st in self.state.values()):
             self.flush()  # a deferred step lives in the gradient rows: apply it before they are really cleared
         for p in self.params:
+            _links.clear_autograd_wrote(p)
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None

@@ -55,6 +55,111 @@ def _collectives_run(world):
     return world > 1 or (os.environ.get("MKB_ROWS_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized())
 
 
+def _lib_collectives_wanted():
+    """MKB_ROWS_PY_COLLECTIVES=1 keeps the step's collectives in torch.distributed (the round-4 form: the A/B switch, and the
+    only form on CPU / gloo)."""
+    return os.environ.get("MKB_ROWS_PY_COLLECTIVES", "0") != "1"
+
+
+class RowsComm:
+    """The library's own RCCL communicators for the row-sharded step (``mkb_rows_comm_*``, mkb_amd/csrc/rows_comm.hip): the
+    step's collectives are issued by ``libmkb_hip.so`` on the step's stream, the look-ahead planning on a side stream, and
+    the all-to-alls' split sizes reach the host through a mailbox the device writes -- no ``torch.distributed`` call, no event
+    wait and no ``.tolist()`` in the loop.  ``torch.distributed`` only carries the 256-byte id blob once, at set-up."""
+
+    SLOTS = 4
+
+    def __init__(self, group, device, max_requests):
+        import ctypes
+
+        lib = _hip.lib()
+        self.world, self.rank, self.device = _world(group), _rank(group), device
+        cap = torch.tensor([int(max_requests)], dtype=torch.int64)
+        blob = torch.zeros(256, dtype=torch.uint8)
+        if self.rank == 0:
+            _hip.check(lib.mkb_rows_comm_unique_id(blob.data_ptr()), "mkb_rows_comm_unique_id")
+        if dist.is_initialized() and self.world >= 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            blob_t, cap_t = (blob.to(device), cap.to(device)) if on_dev else (blob, cap)
+            dist.broadcast(blob_t, src=src, group=group)
+            dist.all_reduce(cap_t, op=dist.ReduceOp.MAX, group=group)  # the id blocks have ONE capacity on every rank
+            blob, cap = blob_t.cpu(), cap_t.cpu()
+        self.max_requests = int(cap.item())
+        handle = ctypes.c_void_p()
+        with _hip.on_device(device):
+            _hip.check(lib.mkb_rows_comm_create(blob.data_ptr(), self.rank, self.world, self.max_requests, ctypes.byref(handle)),
+                       "mkb_rows_comm_create")
+        self._handle = handle
+        self.side = torch.cuda.Stream(device=device)
+        self._n = 0
+        self._I64 = ctypes.c_int64 * self.world
+
+    def next_slot(self):
+        self._n += 1
+        return (self._n - 1) % self.SLOTS
+
+    def plan(self, slot, sample, row0, bufs, bad):
+        b = sample.shape[0]
+        with _hip.on_device(self.device):
+            _hip.check(_hip.lib().mkb_rows_comm_plan(self._handle, slot, _hip.ptr(sample), b, row0, _hip.ptr(bufs["send_ids"]),
+                                                     _hip.ptr(bufs["slot"]), _hip.ptr(bufs["counts"]), _hip.ptr(bufs["compact"]),
+                                                     _hip.ptr(bufs["want"]), bufs["want"].numel(), _hip.ptr(bad),
+                                                     _hip.stream_ptr(self.device), self.side.cuda_stream), "mkb_rows_comm_plan")
+
+    def take(self, slot):
+        sent, wanted = self._I64(), self._I64()
+        with _hip.on_device(self.device):
+            _hip.check(_hip.lib().mkb_rows_comm_take(self._handle, slot, sent, wanted, _hip.stream_ptr(self.device)), "mkb_rows_comm_take")
+        return sent, wanted
+
+    def exchange(self, reduce, send, send_rows, recv, recv_rows, D):
+        with _hip.on_device(self.device):
+            _hip.check(_hip.lib().mkb_rows_comm_exchange(self._handle, _hip.ptr(reduce), 0 if reduce is None else reduce.numel(),
+                                                         _hip.ptr(send), send_rows, _hip.ptr(recv), recv_rows, D,
+                                                         _hip.stream_ptr(self.device)), "mkb_rows_comm_exchange")
+
+    def stats(self):
+        """-> dict(plans, takes_that_waited, waited_with_idle_stream): a take waits when its plan has not executed yet; only
+        those that found the step's stream EMPTY meanwhile left the device without work (the others: the host ran ahead)."""
+        import ctypes
+
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _hip.check(_hip.lib().mkb_rows_comm_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mkb_rows_comm_stats")
+        return {"plans": a.value, "takes_that_waited": b.value, "waited_with_idle_stream": c.value}
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None:
+            torch.cuda.synchronize(self.device)
+            _hip.lib().mkb_rows_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _LibRoute:
+    """A plan made by ``RowsComm.plan``: the same fields the step reads from ``_Route`` (``send_ids``, ``slot``, ``compact``,
+    ``listed`` = [lead | want], ``sc`` / ``rc``), backed by the ring buffers of its plan slot."""
+
+    def __init__(self, comm, slot, bufs, lead, n):
+        self.comm, self.plan_slot, self.bufs, self.lead, self.n = comm, slot, bufs, lead, n
+        self.send_ids, self.slot, self.counts, self.compact = bufs["send_ids"], bufs["slot"], bufs["counts"], bufs["compact"]
+        self.sc = self.rc = self.want = self.listed = None
+
+    def resolve(self, lead=0):
+        if self.want is not None:
+            return
+        assert lead == self.lead
+        self.sc, self.rc = self.comm.take(self.plan_slot)
+        self.n_sent, self.n_wanted = sum(self.sc), sum(self.rc)
+        self.listed = self.bufs["listed"][: lead + self.n_wanted]
+        self.want = self.listed[lead:]
+
+
 class HipRowOps:
     """Row movement on the device (``mkb_rows_route`` / ``mkb_rows_gather`` / ``mkb_rows_scatter_add``).  A segment is
     ``(ids, rows, world, rank, local_ids_out)``: ``world == 0`` -> ``ids`` are shard indices; ``world > 0`` -> global
@@ -339,8 +444,9 @@ class TableRowShardedStep:
         self.world, self.ops = table.world, table.ops
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
-        self._bufs, self._models, self._plan = {}, {}, None
+        self._bufs, self._models, self._plans = {}, {}, []
         self._occ = None
+        self._comm, self._plan_bufs = None, {}
         self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
         if compute is None and self._trains_modulus and modulus is None:
             raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")
@@ -375,19 +481,56 @@ class TableRowShardedStep:
         # the batch as the CALLER holds it (before any .contiguous() copy): a view of the same storage is the same batch
         return (sample.data_ptr(), tuple(sample.shape), tuple(sample.stride()), sample._version, P)
 
+    LOOKAHEAD_MAX = 3  # plans in flight besides the one being consumed (RowsComm.SLOTS - 1)
+
+    def _lib_comm(self, sample):
+        """The library-issued collectives (``RowsComm``) when they apply: collectives run at all, the batch is on a ROCm
+        device, an RCCL runtime is bound, and MKB_ROWS_PY_COLLECTIVES is not set.  Created at the first plan (collectively)."""
+        if self._comm is None:
+            # (an `nccl` group = one rank per GPU, which is what RCCL itself asks for; gloo groups -- CPU tests, several test
+            # ranks on one GPU -- keep the torch.distributed form)
+            ok = (_collectives_run(self.world) and sample.is_cuda and _lib_collectives_wanted() and isinstance(self.ops, HipRowOps)
+                  and dist.is_initialized() and dist.get_backend(self.group) == "nccl" and bool(_hip.lib().mkb_rows_comm_available()))
+            self._comm = RowsComm(self.group, sample.device, 2 * sample.shape[0]) if ok else False
+        return self._comm or None
+
+    def _ring(self, comm, slot, b, P, dev):
+        key = (slot, b, P)
+        bufs = self._plan_bufs.get(key)
+        if bufs is None:
+            cap = P + 2 * b * self.world  # [lead: the pool rows' shard indices | want: at most every request of every rank]
+            listed = torch.empty(cap, dtype=torch.int64, device=dev)
+            bufs = self._plan_bufs[key] = dict(send_ids=torch.empty(2 * b, dtype=torch.int64, device=dev),
+                                               slot=torch.empty(2 * b, dtype=torch.int32, device=dev),
+                                               counts=torch.empty(self.world, dtype=torch.int64, device=dev),
+                                               compact=torch.empty((b, 3), dtype=torch.int64, device=dev),
+                                               listed=listed, want=listed[P:])
+        return bufs
+
     def plan(self, sample, pool_size=None):
-        """Prepare the routing of ``sample``'s positive rows; the NEXT ``step(sample, ...)`` must be for that batch (the same
-        tensor or a view of the same storage, unmodified) and picks it up.  Needs the pool size of that step
-        (``2 * sampler.size``) to address the compact table; defaults to the last step's.
+        """Prepare the routing of ``sample``'s positive rows; plans are consumed in the order they were made: the next
+        ``step(sample, ...)`` without a plan of its own must be for the OLDEST planned batch (the same tensor or a view of the
+        same storage, unmodified).  Needs the pool size of that step (``2 * sampler.size``) to address the compact table;
+        defaults to the last step's.
 
         Every rank must plan (or not plan) alike: a plan issues a collective, so ranks that disagreed would hang.  That is why a
-        pending plan is never dropped silently -- a step for another batch raises (``drop_plan()`` discards it, collectively).
-        On a ROCm device the route kernel and the count exchange run on a side stream, beside the step's own launches."""
+        pending plan is never dropped silently -- a step for another batch raises (``drop_plan()`` discards them, collectively).
+        On a ROCm device the route kernel and the id exchange run on a side stream, beside the step's own launches."""
         P = self._last_P if pool_size is None else pool_size
+        if len(self._plans) >= self.LOOKAHEAD_MAX + 1:
+            raise RuntimeError(f"more than {self.LOOKAHEAD_MAX + 1} batches planned ahead")
         key = self._batch_key(sample, P)
         kept = sample
         sample = sample if sample.is_contiguous() else sample.contiguous()
         _, _, row0, _ = self._layout(P, sample.shape[0])
+        comm = self._lib_comm(sample)
+        if comm is not None:
+            slot = comm.next_slot()
+            bufs = self._ring(comm, slot, sample.shape[0], P, sample.device)
+            comm.plan(slot, sample, row0, bufs, self.ops._flag(sample.device))
+            route = _LibRoute(comm, slot, bufs, P, 2 * sample.shape[0])
+            self._plans.append((key, route, kept, sample))
+            return route
         side = ready = None
         if sample.is_cuda and _collectives_run(self.world):  # (world 1 without collectives: the side stream's events cost more than the 5 us route kernel they hide: 0.246 -> 0.283 ms/step measured)
             side = _Route.side_stream(sample.device)
@@ -406,24 +549,37 @@ class TableRowShardedStep:
             send_ids, slot, counts, compact = self.ops.route(sample, self.world, row0, sample_layout=True)
             route = _Route(self.table, 2 * sample.shape[0], send_ids, slot, counts, compact)
             route.exchange_counts()
-        self._plan = (key, route, kept, sample)  # (keeps the tensors alive: the key stays unique)
+        self._plans.append((key, route, kept, sample))  # (keeps the tensors alive: the key stays unique)
         return route
 
     def drop_plan(self):
-        """Discard a pending plan (every rank must do so alike)."""
-        self._plan = None
+        """Discard every pending plan (every rank must do so alike)."""
+        self._plans = []
+
+    def _plan_ahead(self, upcoming, P):
+        """``upcoming``: the next batch, or a list of the next batches in order; those not planned yet are planned now."""
+        if upcoming is None:
+            return
+        batches = list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming]
+        for i, nxt in enumerate(batches[: self.LOOKAHEAD_MAX]):
+            if i < len(self._plans):
+                if self._plans[i][0] != self._batch_key(nxt, P):
+                    raise RuntimeError("next_sample does not continue the batches already planned (plans are consumed in order)")
+                continue
+            self.plan(nxt, P)
 
     def _route_for(self, sample, P):
-        plan, self._plan = getattr(self, "_plan", None), None
-        if plan is not None:
+        if self._plans:
+            plan = self._plans.pop(0)
             if plan[0] != self._batch_key(sample, P):
+                self._plans.insert(0, plan)
                 raise RuntimeError("the row-sharded step was handed another batch than the one planned for it (plan(next_sample) / "
                                    "next_sample= must name the very next batch, unmodified, with the same pool size, on every rank); "
                                    "call drop_plan() on every rank to discard a plan")
             route = plan[1]
         else:
             self.plan(sample, P)
-            route, self._plan = self._plan[1], None
+            route = self._plans.pop(0)[1]
         route.resolve(lead=P)
         return route
 
@@ -483,9 +639,9 @@ class TableRowShardedStep:
         D, X, row0, rows = self._layout(P, b)
         bufs = self._buffers(P, b, dev)
         ent, grad = bufs["ent"], bufs["grad"]
-        if next_sample is not None:
-            self.plan(next_sample, P)  # its count exchange and read-back overlap this step's kernels
+        self._plan_ahead(next_sample, P)  # their id exchange overlaps this step's kernels
         want = route.want
+        lib = route.comm if isinstance(route, _LibRoute) else None
         R = want.numel()
         # 1. owners: rows about to be read become current (row-lazy Adam), then are read
         opt = _links.owner(tb.data)
@@ -507,11 +663,14 @@ class TableRowShardedStep:
         ops.gather(tb.data.detach(), [(info.pool, ent[:P], self.world, tb.rank, touched[:P]), (want, reply, 0, 0, None)],
                    weight=weight, weight_sum=bufs["wsum"], zero=grad, occ=self._occ)
         # 2. positive rows to their users, pool block (+ weight sum) completed everywhere
-        w_rows = None if direct else route.rows_to_requesters(reply, ent[row0:], async_op=True)
-        w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if _collectives_run(self.world) else None
-        for w in (w_rows, w_pool):
-            if w is not None:
-                w.wait()
+        if lib is not None:  # ONE group on the step's stream: owners send what is wanted, users receive what they sent for
+            lib.exchange(ent[: P + 1], reply, route.rc, ent[row0:], route.sc, D)
+        else:
+            w_rows = None if direct else route.rows_to_requesters(reply, ent[row0:], async_op=True)
+            w_pool = dist.all_reduce(ent[: P + 1], group=self.group, async_op=True) if _collectives_run(self.world) else None
+            for w in (w_rows, w_pool):
+                if w is not None:
+                    w.wait()
         # 3. the training step on the compact table
         rel = self.relation
         if rel.grad is None:
@@ -527,11 +686,14 @@ class TableRowShardedStep:
         # 4. pool-row gradients + relation gradient + loss share (+ modulus gradient): one all-reduce; positive-row
         #    gradients back to their owners
         back = grad[row0: row0 + R] if direct else torch.empty((R, D), dtype=torch.float32, device=dev)
-        w_back = None if direct else route.rows_to_owners(grad[row0:], back, async_op=True)
-        w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if _collectives_run(self.world) else None
-        for w in (w_back, w_sum):
-            if w is not None:
-                w.wait()
+        if lib is not None:
+            lib.exchange(grad[:row0], grad[row0:], route.sc, back, route.rc, D)
+        else:
+            w_back = None if direct else route.rows_to_owners(grad[row0:], back, async_op=True)
+            w_sum = dist.all_reduce(grad[:row0], group=self.group, async_op=True) if _collectives_run(self.world) else None
+            for w in (w_back, w_sum):
+                if w is not None:
+                    w.wait()
         # 5. owners add what they hold; the relation gradient joins relation.grad in the same launch
         ops.scatter_add(tb._grad(), [(info.pool, grad[:P], self.world, tb.rank, None), (want, back, 0, 0, None)],
                         dense_dst=rel.grad, dense_src=bufs["g_rel"], occ=self._occ)

@@ -12,6 +12,22 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+import os
+
+# The -m gpu suite runs on DIRTY device memory with guard bytes behind every cached workspace by default (the two methods that
+# found round 4's defects: a fresh process hands out zero pages, on which reading bytes nobody wrote -- or writing past a buffer --
+# is silent).  Opt out with MKB_TEST_DIRTY_MEMORY=0 / MKB_WS_GUARD=0.  Set before mkb_amd is imported; worker processes inherit.
+os.environ.setdefault("MKB_TEST_DIRTY_MEMORY", "2")
+os.environ.setdefault("MKB_WS_GUARD", "1")
+
+
+def _dirty_gb():
+    try:
+        return float(os.environ.get("MKB_TEST_DIRTY_MEMORY", "0") or 0)
+    except ValueError:
+        return 0.0
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -40,17 +56,15 @@ def liboracle():
 
 @pytest.fixture(autouse=True)
 def _dirty_device_memory(request):
-    """MKB_TEST_DIRTY_MEMORY=<GB>: before every -m gpu test, fill that much device memory with NaN and free it, so that the
-    allocator hands the test dirty blocks instead of the zero pages of a fresh process (a kernel that reads bytes nobody wrote
-    -- or runs past a buffer -- is silent on zero pages).  Off by default (it adds ~0.1 s per test)."""
-    import os
-
-    gb = os.environ.get("MKB_TEST_DIRTY_MEMORY")
-    if gb and request.node.get_closest_marker("gpu") is not None:
+    """MKB_TEST_DIRTY_MEMORY=<GB> (default 2; 0 = off): before every -m gpu test, fill that much device memory with NaN and free
+    it, so that the allocator hands the test dirty blocks instead of the zero pages of a fresh process (a kernel that reads bytes
+    nobody wrote -- or runs past a buffer -- is silent on zero pages).  Adds ~0.1 s per test."""
+    gb = _dirty_gb()
+    if gb > 0 and request.node.get_closest_marker("gpu") is not None:
         import torch
 
         if torch.cuda.is_available():
-            blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(max(1, int(float(gb))))]
+            blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(max(1, int(gb)))]
             torch.cuda.synchronize()
             del blocks
     yield
@@ -58,11 +72,9 @@ def _dirty_device_memory(request):
 
 @pytest.fixture(autouse=True)
 def _workspace_guards(request):
-    """MKB_WS_GUARD=1: after every -m gpu test, the pattern behind each cached pooled-kernel workspace must be intact
+    """MKB_WS_GUARD=1 (the default here; 0 = off): after every -m gpu test, the pattern behind each cached pooled-kernel workspace must be intact
     (mkb_amd.fused.check_workspace_guards)."""
     yield
-    import os
-
     if os.environ.get("MKB_WS_GUARD", "0") == "1" and request.node.get_closest_marker("gpu") is not None:
         from mkb_amd import fused
 

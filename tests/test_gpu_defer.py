@@ -268,3 +268,60 @@ def test_user_code_after_learn_may_clear_gradients_any_way_it_likes():
 
     a, b = run(True), run(False)
     assert a > 0 and abs(a - b) < 1e-6, (a, b)
+
+
+def test_autograd_backward_before_a_fused_step_in_one_optimizer_step_is_not_overwritten():
+    """with ``defer_step`` on, an autograd backward (``model(...)`` + ``loss.backward()``) earlier in the SAME
+    optimizer step accumulates into ``.grad`` without marking rows; the fused step behind it must then accumulate
+    (``rows_clear`` off) instead of storing over those rows, and the optimizer must step every written row.  Compared with
+    ``torch.optim.Adam`` on a twin model that takes both halves through autograd and the general kernels."""
+    from mkb_amd import losses, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+    import mkb_amd.models.base as model_base
+
+    N, R = 5000, 4
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(1)
+    train = np.stack([rs.randint(N, size=3000), rs.randint(R, size=3000), rs.randint(N, size=3000)], 1)
+    t = torch.as_tensor(train).cuda()
+    w = torch.ones(32, device="cuda")
+    crit = losses.Adversarial(alpha=1.0)
+
+    def run(fast):
+        torch.manual_seed(3)
+        m = models.RotatE(hidden_dim=16, entities=ents, relations=rels, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=16, train_triples=train, entities=ents, relations=rels, seed=1)
+        if fast:
+            opt = optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-2, lazy_rows=True, defer_step=True)
+        else:
+            opt = torch.optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-2)
+        step = FusedTrainStep(m, 1.0)
+        for it in range(6):
+            a = t[(2 * it) * 32: (2 * it + 1) * 32].contiguous()
+            b = t[(2 * it + 1) * 32: (2 * it + 2) * 32].contiguous()
+            mixed = it in (2, 3, 5)
+            if mixed or not fast:  # first half through autograd (for the twin: always)
+                neg = ns.generate(a, "head-batch")
+                crit(m(a), m(a, neg.clone() if not fast else neg, "head-batch"), w).backward()
+            else:
+                step(a, w, ns.generate(a, "head-batch"), "head-batch")
+            neg = ns.generate(b, "tail-batch")
+            if fast:
+                step(b, w, neg, "tail-batch")
+            else:
+                crit(m(b), m(b, neg.clone(), "tail-batch"), w).backward()
+            opt.step()
+            opt.zero_grad()
+        if fast:
+            opt.flush()
+        return m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone()
+
+    old = model_base.AUTO_POOL
+    try:
+        model_base.AUTO_POOL = False  # the twin really takes the general kernels
+        ref = run(False)
+    finally:
+        model_base.AUTO_POOL = old
+    got = run(True)
+    for x, y in zip(got, ref):
+        assert torch.allclose(x, y, rtol=0, atol=5e-6), float((x - y).abs().max())

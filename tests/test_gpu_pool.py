@@ -199,21 +199,29 @@ def test_full_size_fused_step_gradients_vs_oracle_on_a_128_row_slice(name):
     ns.check()
 
 
-def test_headline_full_size_every_row_weighted_vs_oracle():
-    """The headline launch with ALL 1024 rows carrying weight (the slice tests above weight 128): loss, every score and BOTH
-    dense gradients against the oracle.  The oracle walks the batch in 8 chunks of 128 rows (memory: [128, 256, 2000] per
-    chunk) -- the loss is a weighted sum over rows with the global normaliser W (adversarial.py:28-29), so the chunks' results,
-    each rescaled by W_chunk / W, add up to the step of the whole batch."""
+EVERY_ROW_CASES = [("RotatE", "head-batch"), ("RotatE", "tail-batch"), ("ComplEx", "head-batch"), ("ComplEx", "tail-batch"),
+                   ("DistMult", "head-batch"), ("DistMult", "tail-batch"), ("TransE", "head-batch"), ("TransE", "tail-batch"),
+                   ("pRotatE", "tail-batch")]
+
+
+@pytest.mark.parametrize("name,mode", EVERY_ROW_CASES)
+def test_headline_full_size_every_row_weighted_vs_oracle(name, mode):
+    """The full-size launch (FB15k-237, hidden 1000, K 256, B 1024) with ALL 1024 rows carrying weight (the slice tests above
+    weight 128): loss, every score and BOTH dense gradients against the oracle, for every model family and both corruption
+    modes (rotate.py:83-97, complex.py:65-85, distmult.py:63-75, transe.py:65-76 -- ComplEx / DistMult run on the matrix
+    route, whose row clamp once hid in the last three batch rows).  The oracle walks the batch in 8 chunks of 128 rows
+    (memory: [128, 256, 2000] per chunk) -- the loss is a weighted sum over rows with the global normaliser W
+    (adversarial.py:28-29), so the chunks' results, each rescaled by W_chunk / W, add up to the step of the whole batch."""
     from mkb_amd import datasets, models, sampling
     from mkb_amd.fused import FusedTrainStep
     from oracle import scoring
 
-    B, K, hidden, name, mode = 1024, 256, 1000, "RotatE", "head-batch"
+    B, K, hidden = 1024, 256, 1000
     ds = datasets.Fb15k237(batch_size=B, shuffle=False, seed=42, num_workers=0)
     torch.manual_seed(12)
     m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=9.0)
     tb = scoring.Tables(name, hidden, 9.0, m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(),
-                        m.modulus.detach().clone())
+                        m.modulus.detach().clone() if hasattr(m, "modulus") else None)
     m = m.cuda()
     ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64))
@@ -689,8 +697,8 @@ def test_full_size_pooled_path_agrees_with_general_kernels_and_oracle_rows(name,
         np.testing.assert_allclose(pos_f.cpu().numpy(), pos_g.detach().cpu().numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(neg_f.cpu().numpy(), neg_g.detach().cpu().numpy(), rtol=0, atol=ATOL)
         np.testing.assert_allclose(loss.item(), err.item(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(g_f[0].cpu().numpy(), m.entity_embedding.grad.cpu().numpy(), rtol=0, atol=1e-5)
-        np.testing.assert_allclose(g_f[1].cpu().numpy(), m.relation_embedding.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        _grad_close(g_f[0].cpu().numpy(), m.entity_embedding.grad.cpu().numpy())
+        _grad_close(g_f[1].cpu().numpy(), m.relation_embedding.grad.cpu().numpy(), rtol=1e-4)
         # (b) oracle on a slice + the loss formula on the step's own scores
         rows = torch.arange(0, 1024, 93)[:12]
         ref = scoring.score(tb, s[rows.cuda()].cpu(), neg[rows.cuda()].cpu(), mode, fast_norm=True)
@@ -726,8 +734,8 @@ def test_every_launch_configuration_agrees_with_general_kernels(name, hidden, mo
         scale = max(1.0, float(np.abs(got["general"][0]).max()))
         np.testing.assert_allclose(got["pooled"][0], got["general"][0], rtol=0, atol=ATOL * scale)
         np.testing.assert_allclose(got["pooled"][1], got["general"][1], rtol=0, atol=1e-5 * scale)
-        np.testing.assert_allclose(got["pooled"][2], got["general"][2], rtol=0, atol=1e-5)
-        np.testing.assert_allclose(got["pooled"][3], got["general"][3], rtol=1e-4, atol=1e-5)
+        _grad_close(got["pooled"][2], got["general"][2])
+        _grad_close(got["pooled"][3], got["general"][3], rtol=1e-4)
     ns.check()
 
 
@@ -762,8 +770,8 @@ def test_foreign_negatives_are_scanned_for_their_shared_pool(name, monkeypatch):
                      m.relation_embedding.grad.cpu().numpy().copy())
     assert len(found) == 1 and found[0] is not None and found[0].pool.numel() == 128  # 512 x 64 slots: scanned once
     np.testing.assert_allclose(got[True][0], got[False][0], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(got[True][1], got[False][1], rtol=0, atol=1e-5)
-    np.testing.assert_allclose(got[True][2], got[False][2], rtol=1e-4, atol=1e-5)
+    _grad_close(got[True][1], got[False][1])
+    _grad_close(got[True][2], got[False][2], rtol=1e-4)
 
 
 def test_diverse_foreign_negatives_stay_on_the_general_kernels():

@@ -294,6 +294,61 @@ def test_rocrand_sampler_rides_the_fused_training_loop():
     assert l1 != l3 and all(np.isfinite(l1))
 
 
+def test_rocrand_set_state_discards_a_pool_drawn_ahead():
+    """A live rocrand sampler in the fused loop always holds a pool drawn AHEAD (it rode the optimizer's launch).  set_state
+    on it must discard that pool and draw from the new counter (mkb_sampler_set_rng kept the stale pool), and an
+    empty batch must move the counter on by one pool."""
+    from mkb_amd import datasets, models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    ds = datasets.Fb15k237(batch_size=128, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    torch.manual_seed(3)
+    m = models.RotatE(hidden_dim=16, entities=ds.entities, relations=ds.relations, gamma=9.0).cuda()
+    ns = sampling.NegativeSampling(size=32, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=9, rng="rocrand")
+    opt = optim.Adam([m.entity_embedding, m.relation_embedding], lr=1e-3, lazy_rows=True, draw_ahead=ns, defer_step=True)
+    step = FusedTrainStep(m, alpha=1.0)
+    w = torch.ones(128, device="cuda")
+    s = train[:128]
+
+    def one():
+        step.sampled(s, w, ns, "tail-batch")
+        opt.step()
+        opt.zero_grad()
+        return step.negative_sample.clone()
+
+    one()
+    state = ns.get_state()        # (a pool is drawn ahead now: the state is the one BEFORE it)
+    a = one()
+    b = one()
+    ns.set_state(*state)          # back to before `a`, with b's successor drawn ahead
+    a2 = one()
+    b2 = one()
+    assert torch.equal(a, a2) and torch.equal(b, b2) and not torch.equal(a, b)
+    # plain generate() path as well, and the empty batch
+    ns.set_state(*state)
+    assert torch.equal(ns.generate(s, "tail-batch"), a)
+    before = ns.get_state()
+    with pytest.raises(RuntimeError):
+        ns.generate(s[:0], "tail-batch")
+    after = ns.get_state()
+    assert after[1][1] == before[1][1] + 1
+    got = ns.generate(s, "tail-batch")  # pool 0 = a, pool 1 went to the empty batch: this is pool 2
+    assert torch.equal(got, _third(ns, state, s))
+    ns.check()
+
+
+def _third(ns, state, s):
+    """The third pool after `state` (pools 0, 1 = a, b), drawn by a plain generate() sequence."""
+    cur = ns.get_state()
+    ns.set_state(*state)
+    ns.generate(s, "tail-batch")
+    ns.generate(s, "tail-batch")
+    out = ns.generate(s, "tail-batch")
+    ns.set_state(*cur)
+    return out
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKB_FUZZ_SEEDS", "12"))))
 def test_random_graph_sampler_vs_c_oracle(liboracle, seed):
     """Random graphs (entity count, relation count, density and hub skew drawn per seed), random K and B: the device sampler

@@ -276,9 +276,9 @@ def _plan_case(rank, world):
     views = [wide[i * B + lo: i * B + hi, :3] for i in range(3)]   # NON-contiguous [b, 3] views of a [3B, 4] table
     assert not views[0].is_contiguous()
     step(views[0], w, neg_of(), "head-batch", next_sample=views[1])        # plans batch 1 while stepping batch 0
-    planned = step._plan is not None
+    planned = len(step._plans) == 1
     step(wide[B + lo: B + hi, :3], w, neg_of(), "tail-batch")              # a fresh view of the same storage: the plan is taken
-    took = step._plan is None
+    took = not step._plans
     step.plan(views[2], 2 * K)
     raised = False
     try:
@@ -288,7 +288,14 @@ def _plan_case(rank, world):
     step.plan(views[2], 2 * K)
     step.drop_plan()
     step(views[0], w, neg_of(), "head-batch")                              # plans inline (every rank alike)
-    return bool(planned and took and raised and len(calls) == 3)
+    # several batches ahead: plans are consumed in the order they were made
+    step(views[0], w, neg_of(), "head-batch", next_sample=[views[1], views[2]])
+    deep = len(step._plans) == 2
+    step(views[1], w, neg_of(), "tail-batch", next_sample=[views[2]])      # already planned: nothing new
+    deep = deep and len(step._plans) == 1
+    step(views[2], w, neg_of(), "tail-batch")
+    deep = deep and not step._plans
+    return bool(planned and took and raised and deep and len(calls) == 6)
 
 
 def test_row_sharded_routes_planned_ahead_are_keyed_alike_on_every_rank():

@@ -58,6 +58,8 @@ def main():
             todo = [(s[lo:hi].contiguous(), w[lo:hi].contiguous(), mode) for s, w, mode in batches()]
             for i, (sl, wl, mode) in enumerate(todo):
                 nxt = todo[i + 1][0] if i + 1 < len(todo) and i != 2 else None  # routes planned one batch ahead (and once not)
+                if nxt is not None and os.environ.get("MKB_TR_LOOKAHEAD", "1") == "2" and i == 0:
+                    nxt = [todo[1][0], todo[2][0]]  # ... and once two batches ahead (plans are consumed in order)
                 if big and i % 2 == 1:  # the sampler riding the shard's optimizer launch (identical negatives)
                     losses.append(step.sampled(sl, wl, ns, mode, next_sample=nxt).item())
                 else:
@@ -66,6 +68,8 @@ def main():
                 opt.step()
                 opt.zero_grad()
             opt.flush()
+            step.check()
+            run.lib = step._comm.stats() if step._comm else None
             return losses, gather_table_rows(table), rel.detach().clone(), None if mod is None else mod.detach().clone()
         model = full.cuda()
         opt = optim.Adam([model.entity_embedding, model.relation_embedding] + ([model.modulus] if name == "pRotatE" else []),
@@ -97,7 +101,8 @@ def main():
         assert float((d > 3e-5).float().mean()) <= 1e-6, float((d > 3e-5).float().mean())
         np.testing.assert_allclose(r1.cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=tol)
         from mkb_amd.table_rows import _collectives_run, _Route
-        print("TR_OK", name, world, backend, "collectives_run", _collectives_run(world), "host_waits", _Route.host_waits)
+        print("TR_OK", name, world, backend, "collectives_run", _collectives_run(world), "host_waits", _Route.host_waits,
+              "lib_collectives", run.lib is not None, run.lib)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -59,9 +59,12 @@ def dirty_device_memory(scale=1.0):
     worker processes of the multi-process tests call this once at their start."""
     import os
 
-    gb = os.environ.get("MKB_TEST_DIRTY_MEMORY")
-    if gb and torch.cuda.is_available():
-        n = max(1, int(float(gb) * scale))
+    try:
+        gb = float(os.environ.get("MKB_TEST_DIRTY_MEMORY", "0") or 0)
+    except ValueError:
+        gb = 0.0
+    if gb > 0 and torch.cuda.is_available():
+        n = max(1, int(gb * scale))
         blocks = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
         torch.cuda.synchronize()
         del blocks
