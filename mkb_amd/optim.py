@@ -200,7 +200,8 @@ class Adam:
     def _rider(self):
         """The dense tensor that steps inside the row-lazy launch (one fewer kernel per step): the first dense,
         16-byte aligned float32 parameter with a gradient, when some table steps row-lazily this time."""
-        lazy = [p for p in self.params if p.grad is not None and _links.owner(p) is self and _links.touched(p) is not None]
+        lazy = [p for p in self.params if p.grad is not None and _links.owner(p) is self and _links.touched(p) is not None
+                and not _links.autograd_wrote(p)]  # (autograd wrote as well: that table takes the dense route this time)
         if len(lazy) != 1:
             return None, None
         for q in self.params:
