@@ -463,6 +463,23 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             const bool on = cp && (g_force_dense >= 0 ? g_force_dense == 1 : (e ? e[0] == '1' : true));  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
             if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
+        // Small problems: when the single-pass grid would be a handful of 16-wave workgroups, its ring and its prologue ARE the
+        // launch (Umls TransE-64, K 16, B 256: two workgroups, 43 us for 0.5 MFLOP).  One wave per (row tile, <= 64 positions,
+        // 64 * kpt units) instead: pool_bwd_wave_kernel; position slices until ~1024 waves are in flight.  MKB_POOL_SMALL=0: A/B.
+        L.small = 0; L.skpt = 1; L.schunks = 1;
+        if (L.bwd1) {
+            const char *e = getenv("MKB_POOL_SMALL");
+            const int groups1 = (row_tiles + 15) / 16;
+            const int skpt = L.kpt >= 2 ? 2 : 1;
+            const int chunks = (NU + 64 * skpt - 1) / (64 * skpt);
+            int nsl = (int)((P + 63) / 64);
+            while (nsl < kMaxSlices && (int64_t)row_tiles * chunks * nsl < 1024 && P / nsl > 2) ++nsl;
+            const int limit = e && atoi(e) > 1 ? atoi(e) : 32;  // (MKB_POOL_SMALL=<n>: the workgroup count below which it applies)
+            if (!(e && e[0] == '0') && (int64_t)groups1 * npb * L.dim_slices <= limit && nsl <= kMaxSlices) {
+                L.small = 1; L.bwd1 = 0; L.skpt = skpt; L.schunks = chunks; L.q_slices = nsl;
+                L.dense_lanes = 0; L.pb_halves = 0;
+            }
+        }
         if (L.bwd1) {
             const int64_t waves = (int64_t)row_tiles * L.dim_slices * npb;
             L.tiles_per_wave = (int)(waves >= 3 * 4096 ? waves / (2 * 4096) : 1);
@@ -472,7 +489,7 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
         }
     }
     if (const char *e = getenv("MKB_POOL_FSLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) L.fwd_slices = v; }
-    if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma && !L.bwd1) L.q_slices = v; }
+    if (const char *e = getenv("MKB_POOL_QSLICES")) { const int v = atoi(e); if (v >= 1 && v <= kMaxSlices && !L.mfma && !L.bwd1 && !L.small) L.q_slices = v; }
     if (const char *e = getenv("MKB_POOL_XSLICES")) { const int v = atoi(e); if (v >= min_x && v >= 1) L.x_slices = v; }
     return true;
 }
@@ -665,6 +682,9 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
         if (L.bwd1) {  // every pair term evaluated once (pool_bwd1_kernel); profiled as the POOL_BWD_Q class
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
             if (int rc = launcher_of(tb->model)(4, head, L, A, st)) return rc;
+        } else if (L.small) {  // a small problem: one wave per piece, every pair evaluated once (pool_bwd_wave_kernel)
+            ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+            if (int rc = launcher_of(tb->model)(6, head, L, A, st)) return rc;
         } else if (!split) {  // dq and dx passes in one grid (pool_bwd_kernel); profiled as the POOL_BWD_Q class
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
             if (int rc = launcher_of(tb->model)(1, head, L, A, st)) return rc;

@@ -693,6 +693,121 @@ __global__ __launch_bounds__(NW * 64) void pool_bwd_kernel(PoolArgs A) {
     else pool_bwd_q_body<MODEL, HEAD, KPT, NW>(A, b - A.x_blocks, lds_bwd);
 }
 
+// ------------------------------------------------------------------------------------------------ backward: small problems
+// pool_bwd_wave: when the whole backward is a handful of row groups (Umls: 256 rows x 32 positions x 64 dims = 0.5 MFLOP), the
+// single-pass kernel's skeleton IS the launch: two 16-wave workgroups walking a 16-phase ring took 43 us there, the two-pass
+// kernel 36.  Here one WAVE = (tile of 8 rows, slice of <= 64 pool positions, 64 * KPT units): no LDS, no ring, no workgroup.
+// Lane j holds the 8 seeds and the table offset of the slice's j-th position (plain [B, P] seed layout); the used positions
+// (any seed != 0) are walked off a ballot mask with their candidate rows requested four ahead.  Every pair term is evaluated
+// once: dq accumulates in registers and is stored to the slice's dQ partial buffer (the row backward adds the slices up),
+// the position's dx goes to the table gradient with one fp32 atomic per element (row tiles x used positions x units of
+// them: 65 k at the Umls shape).
+template <int MODEL, bool HEAD, int KPT>
+__global__ __launch_bounds__(64) void pool_bwd_wave_kernel(PoolArgs A) {
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
+    constexpr int R = 4;  // candidate rows in flight
+    const int lane = threadIdx.x;
+    const int tile = (int)blockIdx.x, sl = (int)blockIdx.y, chunk = (int)blockIdx.z;
+    const int nsl = A.q_slices;
+    const int NU = CP ? A.d : (int)A.De;
+    const int u0 = (chunk * 64 + lane) * KPT;
+    const int i0 = tile * TI;
+    const int npos = (A.P - sl + nsl - 1) / nsl;  // positions p = sl + nsl * j, j < npos <= 64 (host: nsl >= ceil(P / 64))
+    float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
+#pragma unroll
+    for (int r = 0; r < TI; ++r) load_units<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+    const int p_own = sl + nsl * lane;
+    const bool valid = lane < npos && p_own < A.P;
+    float gv[TI];
+    unsigned nz = 0;
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+        gv[r] = (valid && i0 + r < A.B) ? A.G[(int64_t)(i0 + r) * A.P + p_own] : 0.f;
+        nz |= __float_as_uint(gv[r]) << 1;  // (+-0 = the row does not use the position: the loss kernel writes 0 there)
+    }
+    const int64_t off = (valid ? A.pool[p_own] : 0) * A.De;
+    const int off_lo = (int)(unsigned)off, off_hi = (int)(off >> 32);
+    unsigned long long req = __ballot(nz != 0);  // positions not requested yet (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < TI; ++r) {
+#pragma unroll
+        for (int v = 0; v < KPT; ++v) {
+            if (i0 + r >= A.B) { q0[r][v] = 0.f; q1[r][v] = 0.f; }
+            dq0[r][v] = 0.f; dq1[r][v] = 0.f;
+        }
+    }
+    const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
+    float extra = 0.f;
+    auto take = [&]() {  // the next used position of the slice, or -1
+        if (!req) return -1;
+        const int j = (int)__builtin_ctzll(req);
+        req &= req - 1ull;
+        return j;
+    };
+    auto offset_of = [&](int j) {
+        return ((int64_t)__builtin_amdgcn_readlane(off_hi, j) << 32) | (int64_t)(unsigned)__builtin_amdgcn_readlane(off_lo, j);
+    };
+    float xr0[R][KPT], xr1[R][KPT];
+    int jr[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        jr[k] = take();
+        load_units<CP, KPT>(A.ent + offset_of(max(jr[k], 0)), A.d, NU, u0, xr0[k], xr1[k]);
+    }
+    for (bool more = true; more;) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int j = jr[k];
+            if (j < 0) { more = false; break; }
+            float x0[KPT], x1[KPT];
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { x0[v] = xr0[k][v]; x1[v] = xr1[k][v]; }
+            const int64_t xoff = offset_of(j);
+            jr[k] = take();
+            load_units<CP, KPT>(A.ent + offset_of(max(jr[k], 0)), A.d, NU, u0, xr0[k], xr1[k]);
+            float dx0[KPT], dx1[KPT];
+#pragma unroll
+            for (int v = 0; v < KPT; ++v) { dx0[v] = 0.f; dx1[v] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < TI; ++r) {
+                const float g = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(gv[r]), j));
+                if ((__float_as_uint(g) << 1) == 0u) continue;  // (wave-uniform)
+#pragma unroll
+                for (int v = 0; v < KPT; ++v) {
+                    if constexpr (CP) {
+                        Cplx dq, dx;
+                        pair_bwd_cmod(Cplx{q0[r][v], q1[r][v]}, Cplx{x0[v], x1[v]}, g, dq, dx);
+                        dq0[r][v] += dq.re; dq1[r][v] += dq.im;
+                        dx0[v] += dx.re; dx1[v] += dx.im;
+                    } else {
+                        float dq, dx, e0 = 0.f;
+                        pair_bwd_real<MODEL, HEAD>(q0[r][v], x0[v], g, A.kd, modulus, dq, dx, e0);
+                        dq0[r][v] += dq;
+                        dx0[v] += dx;
+                        extra += g * e0;
+                    }
+                }
+            }
+            if (u0 < NU) {
+                float *grow = A.g_ent + xoff;
+#pragma unroll
+                for (int v = 0; v < KPT; ++v) {
+                    atomicAdd(grow + u0 + v, dx0[v]);
+                    if constexpr (CP) atomicAdd(grow + A.d + u0 + v, dx1[v]);
+                }
+            }
+        }
+    }
+    float *dQs = A.dQ + (int64_t)sl * A.B * A.De;
+#pragma unroll
+    for (int r = 0; r < TI; ++r)
+        if (i0 + r < A.B) store_units<CP, KPT>(dQs + (int64_t)(i0 + r) * A.De, A.d, NU, u0, dq0[r], dq1[r]);
+    if constexpr (MODEL == MKB_PROTATE) {  // d score / d modulus = - sum_k |sin z|   (protate.py:91)
+        extra = wave_sum(extra);
+        if (lane == 0 && extra != 0.f) atomicAdd(A.g_modulus, -extra);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: single pass
 // pool_bwd1: every (row, pool position, unit) pair term is evaluated ONCE and feeds both gradients.
 //   workgroup = (dim slice of 64*KPT units, group of 16*tiles_per_wave row tiles, block of <= 64*halves pool positions;
@@ -1610,13 +1725,14 @@ struct PoolLaunch {
     int dim_slices, pb_halves, tiles_per_wave, row_groups, cplx;
     int dense_lanes;      // lanes of every half that hold dense-prefix positions (pool_bwd1_kernel's dense pass; 0 = none)
     int tile, tile_kd, tile_ks, tile_fringe_slices;  // forward: dense prefix [0, tile_kd) on the register tile (score_pool_tile.h)
+    int small, skpt, schunks;  // backward of a small problem: pool_bwd_wave_kernel (q_slices position slices, skpt units per lane, schunks dim chunks)
     int rel_copies;       // > 1: copies of the relation gradient the row backward spreads its atomics over (few relations)
     int64_t rel_elems;    // n_relation * relation_dim
     int64_t n_entity;
 };
 
 // Per-model entry points (defined in score_pool_<model>.hip): launch one of the three kernels for (head, config).
-typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd, 5 fwd: tile + fringe*/, bool head, const PoolLaunch &L, const PoolArgs &A,
+typedef int (*pool_launch_fn)(int which /*0 fwd, 1 bwd (dq + dx in one grid), 2 dx pass alone, 3 dq pass alone, 4 single-pass bwd, 5 fwd: tile + fringe, 6 bwd of a small problem (one wave per piece)*/, bool head, const PoolLaunch &L, const PoolArgs &A,
                               hipStream_t st);
 int pool_launch_transe(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
 int pool_launch_rotate(int, bool, const PoolLaunch &, const PoolArgs &, hipStream_t);
@@ -1696,9 +1812,20 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
 template <int MODEL, bool HEAD>
 static int launch_fwd_tile(const PoolLaunch &L, const PoolArgs &A, hipStream_t st, float *part, GemmTail *tail);  // score_pool_tile.h
 
+template <int MODEL, bool HEAD, int KPT>
+static int launch_wave(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
+    PoolArgs A2 = A;
+    A2.q_slices = L.q_slices;
+    const dim3 grid((unsigned)((A.B + TI - 1) / TI), (unsigned)L.q_slices, (unsigned)L.schunks);
+    hipLaunchKernelGGL((pool_bwd_wave_kernel<MODEL, HEAD, KPT>), grid, dim3(64), 0, st, A2);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 template <int MODEL, bool HEAD>
 static int launch_head(int which, const PoolLaunch &L0, const PoolArgs &A, hipStream_t st) {
     if (which == 5) return launch_fwd_tile<MODEL, HEAD>(L0, A, st, A.tile_part, A.tile_tail);
+    if (which == 6) return L0.skpt == 2 ? launch_wave<MODEL, HEAD, 2>(L0, A, st) : launch_wave<MODEL, HEAD, 1>(L0, A, st);
     if (which == 4) {
         if constexpr (!ModelTraits<MODEL>::cplx_pair && MODEL != MKB_PROTATE)
             if (L0.bkpt == 4) return launch_bwd1<MODEL, HEAD, 4>(L0, A, st);
