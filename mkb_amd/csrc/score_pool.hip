@@ -386,12 +386,15 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
     {
         static const bool off = getenv("MKB_POOL_TILE") && getenv("MKB_POOL_TILE")[0] == '0';  // A/B switch
         const int64_t Kd = (P / 2) / 64 * 64;
-        if (!off && cp && !use_mfma(tb) && al16 && d % 4 == 0 && L.fnw == 4 && (L.fkpt == 4 || L.fkpt == 2) && Kd >= 64 && B >= 64) {
+        // (round 5: TransE's |q - x| on the same tile -- its "dims" are pairs of floats, so that a chunk is 32 floats either way)
+        const bool te = tb->model == MKB_TRANSE && De % 4 == 0;
+        const int64_t dt = cp ? d : De / 2;
+        if (!off && (te || (cp && d % 4 == 0)) && !use_mfma(tb) && al16 && L.fnw == 4 && (L.fkpt == 4 || L.fkpt == 2) && Kd >= 64 && B >= 64) {
             L.tile = 1;
             L.tile_kd = (int)Kd;
             const int tiles = (int)((B + 63) / 64) * (int)(Kd / 64);
             int ks = 1;
-            while (tiles * ks < 512 && ks < 16 && d / (ks * 2) >= 32) ks *= 2;  // fill the chip; >= 2 chunks of 16 dims per split
+            while (tiles * ks < 512 && ks < 16 && dt / (ks * 2) >= 32) ks *= 2;  // fill the chip; >= 2 chunks of 16 dims per split
             if (const char *e = getenv("MKB_POOL_TILE_KS")) { const int v = atoi(e); if (v >= 1 && v <= 16) ks = v; }
             L.tile_ks = ks;
             L.tile_fringe_slices = 2;

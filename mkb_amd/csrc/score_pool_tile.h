@@ -34,9 +34,26 @@ struct TileArgs {
     int row_tiles, pos_tiles;         // dense grid: row_tiles x pos_tiles x ks workgroups behind them
 };
 
+// Round 5: the same tile for TransE's pair function |q - x| (transe.py:70-75).  A GROUP is the float4 a lane's packed step works
+// on: two complex dims (re_k, re_k+1, im_k, im_k+1) for the complex modulus, four consecutive floats for the real-valued
+// term; a chunk = kTileKC / 2 groups either way, so the staging, the LDS images and the 4 x 4 accumulators are shared and only
+// the loads' addresses and the pair function differ.  The real-valued term is 2 VALU operations per element against 8
+// ds_read_b128 per 64 elements and lane: the LDS array is busy about half the time.
+template <int MODEL, bool HEAD>
+__device__ __forceinline__ f2 tile_pair_term(float4 q, float4 x) {
+    if constexpr (ModelTraits<MODEL>::cplx_pair) {
+        return pair_term_cmod2(f2{q.x, q.y}, f2{q.z, q.w}, f2{x.x, x.y}, f2{x.z, x.w});
+    } else {
+        static_assert(MODEL == MKB_TRANSE, "real-valued tile: TransE's |q - x| only");
+        const f2 a = HEAD ? f2{x.x, x.y} + f2{q.x, q.y} : f2{q.x, q.y} - f2{x.x, x.y};
+        const f2 b = HEAD ? f2{x.z, x.w} + f2{q.z, q.w} : f2{q.z, q.w} - f2{x.z, x.w};
+        return f2{__builtin_fabsf(a.x) + __builtin_fabsf(b.x), __builtin_fabsf(a.y) + __builtin_fabsf(b.y)};
+    }
+}
+
 template <int MODEL, bool HEAD, int KPT>
 __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs T) {
-    static_assert(ModelTraits<MODEL>::cplx_pair, "the tile is written for the complex-modulus pair function");
+    constexpr bool CP = ModelTraits<MODEL>::cplx_pair;
     extern __shared__ __attribute__((aligned(16))) int lds_tile_dyn[];  // the fringe workgroups' position lists
     const int b = (int)blockIdx.x;
     const int n_fringe = T.fringe_tiles * T.fringe_slices;
@@ -52,30 +69,49 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 7, lp = lane >> 3;
     const int wr = (wave >> 1) * 32, wp = (wave & 1) * 32;
-    const int d = A.d;
+    // k counts "dims": complex dims for the complex modulus (two per group), PAIRS of floats for the real-valued term (two per
+    // group as well: a chunk of kTileKC dims = kTileKC / 2 groups = 32 floats of a row either way)
+    const int d = CP ? A.d : (int)(A.De / 2);
     const int kper = ((d + T.ks - 1) / T.ks + kTileKC - 1) / kTileKC * kTileKC;
     const int k_lo = z * kper, k_hi = min(d, k_lo + kper);
 
-    // staging: thread -> (row of the tile, quad of dims): one float4 of each half per operand and chunk
+    // staging: thread -> (row of the tile, quad of dims): two groups per operand and chunk (complex: one float4 of each half,
+    // real: two consecutive float4)
     const int srow = tid >> 2, skq = tid & 3;
     const float *qsrc = A.Q + (int64_t)min(i0 + srow, A.B - 1) * A.De;
     const float *xsrc = A.ent + A.pool[min(p0 + srow, T.Kd - 1)] * A.De;
     float4 rq_re, rq_im, rx_re, rx_im;
     auto gload = [&](int k0) {
-        const int k = min(k0 + 4 * skq, d - 4);
-        rq_re = *reinterpret_cast<const float4 *>(qsrc + k);
-        rq_im = *reinterpret_cast<const float4 *>(qsrc + d + k);
-        rx_re = *reinterpret_cast<const float4 *>(xsrc + k);
-        rx_im = *reinterpret_cast<const float4 *>(xsrc + d + k);
+        if constexpr (CP) {
+            const int k = min(k0 + 4 * skq, d - 4);
+            rq_re = *reinterpret_cast<const float4 *>(qsrc + k);
+            rq_im = *reinterpret_cast<const float4 *>(qsrc + d + k);
+            rx_re = *reinterpret_cast<const float4 *>(xsrc + k);
+            rx_im = *reinterpret_cast<const float4 *>(xsrc + d + k);
+        } else {  // groups g, g + 1 = floats [2 k, 2 k + 8) of the row (De is a multiple of 4: the last group may stand alone)
+            const int f0 = min(2 * (k0 + 4 * skq), (int)A.De - 4), f1 = min(2 * (k0 + 4 * skq) + 4, (int)A.De - 4);
+            rq_re = *reinterpret_cast<const float4 *>(qsrc + f0);
+            rq_im = *reinterpret_cast<const float4 *>(qsrc + f1);
+            rx_re = *reinterpret_cast<const float4 *>(xsrc + f0);
+            rx_im = *reinterpret_cast<const float4 *>(xsrc + f1);
+        }
     };
     auto lstore = [&](int buf, int k0) {
-        const bool ok = k0 + 4 * skq < k_hi;  // dims past the split's range contribute |0 - 0| = 0
         const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 a = ok ? rq_re : zz, bq = ok ? rq_im : zz, c = ok ? rx_re : zz, e = ok ? rx_im : zz;
-        *reinterpret_cast<float4 *>(&sq[buf][2 * skq][srow * 4]) = make_float4(a.x, a.y, bq.x, bq.y);
-        *reinterpret_cast<float4 *>(&sq[buf][2 * skq + 1][srow * 4]) = make_float4(a.z, a.w, bq.z, bq.w);
-        *reinterpret_cast<float4 *>(&sx[buf][2 * skq][srow * 4]) = make_float4(c.x, c.y, e.x, e.y);
-        *reinterpret_cast<float4 *>(&sx[buf][2 * skq + 1][srow * 4]) = make_float4(c.z, c.w, e.z, e.w);
+        if constexpr (CP) {
+            const bool ok = k0 + 4 * skq < k_hi;  // dims past the split's range contribute |0 - 0| = 0
+            const float4 a = ok ? rq_re : zz, bq = ok ? rq_im : zz, c = ok ? rx_re : zz, e = ok ? rx_im : zz;
+            *reinterpret_cast<float4 *>(&sq[buf][2 * skq][srow * 4]) = make_float4(a.x, a.y, bq.x, bq.y);
+            *reinterpret_cast<float4 *>(&sq[buf][2 * skq + 1][srow * 4]) = make_float4(a.z, a.w, bq.z, bq.w);
+            *reinterpret_cast<float4 *>(&sx[buf][2 * skq][srow * 4]) = make_float4(c.x, c.y, e.x, e.y);
+            *reinterpret_cast<float4 *>(&sx[buf][2 * skq + 1][srow * 4]) = make_float4(c.z, c.w, e.z, e.w);
+        } else {
+            const bool ok0 = k0 + 4 * skq < k_hi, ok1 = k0 + 4 * skq + 2 < k_hi;
+            *reinterpret_cast<float4 *>(&sq[buf][2 * skq][srow * 4]) = ok0 ? rq_re : zz;
+            *reinterpret_cast<float4 *>(&sq[buf][2 * skq + 1][srow * 4]) = ok1 ? rq_im : zz;
+            *reinterpret_cast<float4 *>(&sx[buf][2 * skq][srow * 4]) = ok0 ? rx_re : zz;
+            *reinterpret_cast<float4 *>(&sx[buf][2 * skq + 1][srow * 4]) = ok1 ? rx_im : zz;
+        }
     };
     f2 acc[4][4];
 #pragma unroll
@@ -102,7 +138,7 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    acc[a][c] += pair_term_cmod2(f2{q[a].x, q[a].y}, f2{q[a].z, q[a].w}, f2{x[c].x, x[c].y}, f2{x[c].z, x[c].w});
+                    acc[a][c] += tile_pair_term<MODEL, HEAD>(q[a], x[c]);
         }
         if (more) lstore(buf ^ 1, k0 + kTileKC);
         __syncthreads();
@@ -137,8 +173,8 @@ __global__ __launch_bounds__(256) void tile_scores_reduce_kernel(const float *__
 // tail: non-null = the consumer adds the partial sums up itself (described in *tail, kind 3); null = S is finished here
 template <int MODEL, bool HEAD>
 static int launch_fwd_tile(const PoolLaunch &L, const PoolArgs &A0, hipStream_t st, float *part, GemmTail *tail) {
-    if constexpr (!ModelTraits<MODEL>::cplx_pair) {
-        return set_error(MKB_ERR_UNSUPPORTED, "pool_fwd_tile: complex-modulus pair function only");
+    if constexpr (!ModelTraits<MODEL>::cplx_pair && MODEL != MKB_TRANSE) {
+        return set_error(MKB_ERR_UNSUPPORTED, "pool_fwd_tile: complex-modulus pair function and TransE only");
     } else {
         PoolArgs A = A0;
         TileArgs T{};

@@ -10,7 +10,7 @@
 """
 import torch
 
-from . import _hip, _links
+from . import _gradshare, _hip, _links
 from .sampling.negative_sampling import PoolInfo
 
 __all__ = ["FusedTrainStep", "pooled_forward", "pooled_supported"]
@@ -83,7 +83,8 @@ class _PoolScoreFn(torch.autograd.Function):
         B, K = sample.shape[0], info.size
         G = torch.zeros((B, 2 * K), dtype=torch.float32, device=ent.device)
         G.scatter_add_(1, info.pos.long(), _hip.contiguous(dneg, torch.float32))
-        g_ent, g_rel = torch.zeros_like(ent), torch.zeros_like(rel)
+        g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)  # (shared with the positive scores' backward of this pass)
+        g_rel, fresh_r = _gradshare.take(model.relation_embedding, rel)
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
         ws = _workspace(model, B, K)
@@ -91,7 +92,7 @@ class _PoolScoreFn(torch.autograd.Function):
             _hip.check(_hip.lib().mkb_pool_score_bwd(model._tables(ent, rel, modulus), gr, _hip.ptr(sample),
                                                      _hip.ptr(info.pool), _hip.ptr(info.cnt), B, K, ctx.mode, _hip.ptr(G),
                                                      _hip.ptr(ws), _hip.stream_ptr()), "mkb_pool_score_bwd")
-        return g_ent, g_rel, g_mod, None, None, None, None
+        return (g_ent if fresh_e else None), (g_rel if fresh_r else None), g_mod, None, None, None, None
 
 
 def pooled_forward(model, sample, info, mode_id):

@@ -18,7 +18,7 @@ import pickle
 import torch
 import torch.nn as nn
 
-from .. import _hip, _links
+from .. import _gradshare, _hip, _links
 from ..sampling.negative_sampling import PoolInfo
 from ..utils.fmt import aligned_block
 
@@ -58,7 +58,9 @@ class _ScoreFn(torch.autograd.Function):
         B = sample.shape[0]
         K = 1 if cand is None else cand.shape[1]
         dscore = _hip.contiguous(dscore, torch.float32)
-        g_ent, g_rel = torch.zeros_like(ent), torch.zeros_like(rel)
+        # (one dense buffer per table and backward pass: the positive and the negative score functions of a step share it)
+        g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)
+        g_rel, fresh_r = _gradshare.take(model.relation_embedding, rel)
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         tb = model._tables(ent, rel, modulus)
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())
@@ -67,7 +69,7 @@ class _ScoreFn(torch.autograd.Function):
             ws = _hip.aligned_bytes(n_ws, ent.device) if n_ws > 0 else None
             _hip.check(_hip.lib().mkb_score_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(cand), B, K, ctx.mode,
                                                 _hip.ptr(dscore), _hip.ptr(ws), _hip.stream_ptr()), "mkb_score_bwd")
-        return g_ent, g_rel, g_mod, None, None, None, None
+        return (g_ent if fresh_e else None), (g_rel if fresh_r else None), g_mod, None, None, None, None
 
 
 class Base(nn.Module):
