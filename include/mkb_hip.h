@@ -313,8 +313,8 @@ int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp
  * mkb_rows_comm_take: the split sizes of that plan -- sent_host [world] rows this rank asks each owner for, wanted_host [world]
  *   rows each rank asks this owner for -- read from a host-coherent mailbox the plan's last kernel wrote (no HIP call; spins
  *   only when the plan has not executed yet), and `stream` is made to wait for the plan.
- * mkb_rows_comm_exchange: ONE RCCL group on `stream`: all-reduce (sum, in place) of reduce [reduce_n] floats (0 = none) and the
- *   all-to-all of rows of D floats: send_rows_host[p] rows to rank p from `send` (consecutive), recv_rows_host[p] rows from
+ * mkb_rows_comm_exchange: on `stream`: the all-reduce (sum, in place) of reduce [reduce_n] floats (0 = none), then ONE RCCL
+ *   group with the all-to-all of rows of D floats (MKB_ROWS_ONE_GROUP=1, and always at world 1: both in one group): send_rows_host[p] rows to rank p from `send` (consecutive), recv_rows_host[p] rows from
  *   rank p into `recv` (null count vectors = no all-to-all).  Forward: owners send `wanted`, users receive `sent`; the
  *   gradients' way back swaps the two.
  * mkb_rows_comm_stats: plans made, takes that found their plan not executed yet, and how many of those found `stream` idle

@@ -23,6 +23,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -288,8 +289,17 @@ extern "C" int mkb_rows_comm_exchange(mkb_rows_comm_t *c, float *reduce, int64_t
     MKB_REQUIRE(c != nullptr && D > 0 && reduce_n >= 0, "bad arguments");
     MKB_REQUIRE(reduce_n == 0 || reduce, "null all-reduce buffer");
     hipStream_t st = (hipStream_t)stream;
+    // One group for both by default at world 1 only: whether RCCL accepts a collective and point-to-point calls in ONE group
+    // could not be exercised across GPUs here (1-GPU boxes), so with several ranks the all-reduce goes first, on its own, and
+    // the sends / receives form the group behind it: two launches each way, the same order on every rank.  MKB_ROWS_ONE_GROUP=1
+    // merges them (one launch less) once that has been seen to work on the node at hand.
+    static const bool one_group_env = getenv("MKB_ROWS_ONE_GROUP") && getenv("MKB_ROWS_ONE_GROUP")[0] == '1';
+    const bool one_group = one_group_env || c->world == 1;
+    if (!one_group && reduce_n > 0)
+        MKB_CHECK_NCCL(rccl().AllReduce(reduce, reduce, (size_t)reduce_n, ncclFloat32, ncclSum, c->step_comm, st));
     MKB_CHECK_NCCL(rccl().GroupStart());
-    if (reduce_n > 0) MKB_CHECK_NCCL(rccl().AllReduce(reduce, reduce, (size_t)reduce_n, ncclFloat32, ncclSum, c->step_comm, st));
+    if (one_group && reduce_n > 0)
+        MKB_CHECK_NCCL(rccl().AllReduce(reduce, reduce, (size_t)reduce_n, ncclFloat32, ncclSum, c->step_comm, st));
     if (send_rows_host && recv_rows_host) {
         int64_t so = 0, ro = 0;
         for (int p = 0; p < c->world; ++p) {

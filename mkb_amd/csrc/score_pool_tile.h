@@ -22,7 +22,11 @@
 
 namespace mkb {
 
-constexpr int kTileKC = 16;                     // dims per LDS chunk
+#ifndef MKB_TILE_KC
+#define MKB_TILE_KC 16
+#endif
+constexpr int kTileKC = MKB_TILE_KC;            // dims per LDS chunk (a multiple of 16: every staging thread moves kTileKC / 16 quads of dims)
+constexpr int kTileNQ = kTileKC / 16;
 // (the k-pair loop below stays rolled: unrolled 2 or 4 times it is no faster -- 57.7 vs 57.0 us in round 4's A/B --, 8 times 83 us)
 constexpr int kTileRows = 64, kTilePos = 64;    // workgroup tile (2 x 2 waves of 32 x 32)
 constexpr int kTilePitch = kTileRows * 4 + 4;   // floats per k-pair row of the LDS image (+ 16 B pad)
@@ -47,7 +51,12 @@ __device__ __forceinline__ f2 tile_pair_term(float4 q, float4 x) {
         static_assert(MODEL == MKB_TRANSE, "real-valued tile: TransE's |q - x| only");
         const f2 a = HEAD ? f2{x.x, x.y} + f2{q.x, q.y} : f2{q.x, q.y} - f2{x.x, x.y};
         const f2 b = HEAD ? f2{x.z, x.w} + f2{q.z, q.w} : f2{q.z, q.w} - f2{x.z, x.w};
-        return f2{__builtin_fabsf(a.x) + __builtin_fabsf(b.x), __builtin_fabsf(a.y) + __builtin_fabsf(b.y)};
+        // |a| + |b| as ONE v_add_f32 with both source modifiers (left to itself the compiler clears the sign bits with four
+        // v_and_b32 and adds packed: 8 instructions per group of four elements instead of 5)
+        f2 r;
+        asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+        asm("v_add_f32 %0, |%1|, |%2|" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+        return r;
     }
 }
 
@@ -80,37 +89,45 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
     const int srow = tid >> 2, skq = tid & 3;
     const float *qsrc = A.Q + (int64_t)min(i0 + srow, A.B - 1) * A.De;
     const float *xsrc = A.ent + A.pool[min(p0 + srow, T.Kd - 1)] * A.De;
-    float4 rq_re, rq_im, rx_re, rx_im;
+    float4 rq_re[kTileNQ], rq_im[kTileNQ], rx_re[kTileNQ], rx_im[kTileNQ];
     auto gload = [&](int k0) {
-        if constexpr (CP) {
-            const int k = min(k0 + 4 * skq, d - 4);
-            rq_re = *reinterpret_cast<const float4 *>(qsrc + k);
-            rq_im = *reinterpret_cast<const float4 *>(qsrc + d + k);
-            rx_re = *reinterpret_cast<const float4 *>(xsrc + k);
-            rx_im = *reinterpret_cast<const float4 *>(xsrc + d + k);
-        } else {  // groups g, g + 1 = floats [2 k, 2 k + 8) of the row (De is a multiple of 4: the last group may stand alone)
-            const int f0 = min(2 * (k0 + 4 * skq), (int)A.De - 4), f1 = min(2 * (k0 + 4 * skq) + 4, (int)A.De - 4);
-            rq_re = *reinterpret_cast<const float4 *>(qsrc + f0);
-            rq_im = *reinterpret_cast<const float4 *>(qsrc + f1);
-            rx_re = *reinterpret_cast<const float4 *>(xsrc + f0);
-            rx_im = *reinterpret_cast<const float4 *>(xsrc + f1);
+#pragma unroll
+        for (int j = 0; j < kTileNQ; ++j) {
+            const int kq = k0 + 4 * (skq + 4 * j);  // first dim of this thread's j-th quad
+            if constexpr (CP) {
+                const int k = min(kq, d - 4);
+                rq_re[j] = *reinterpret_cast<const float4 *>(qsrc + k);
+                rq_im[j] = *reinterpret_cast<const float4 *>(qsrc + d + k);
+                rx_re[j] = *reinterpret_cast<const float4 *>(xsrc + k);
+                rx_im[j] = *reinterpret_cast<const float4 *>(xsrc + d + k);
+            } else {  // groups g, g + 1 = floats [2 k, 2 k + 8) of the row (De is a multiple of 4: the last group may stand alone)
+                const int f0 = min(2 * kq, (int)A.De - 4), f1 = min(2 * kq + 4, (int)A.De - 4);
+                rq_re[j] = *reinterpret_cast<const float4 *>(qsrc + f0);
+                rq_im[j] = *reinterpret_cast<const float4 *>(qsrc + f1);
+                rx_re[j] = *reinterpret_cast<const float4 *>(xsrc + f0);
+                rx_im[j] = *reinterpret_cast<const float4 *>(xsrc + f1);
+            }
         }
     };
     auto lstore = [&](int buf, int k0) {
         const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (CP) {
-            const bool ok = k0 + 4 * skq < k_hi;  // dims past the split's range contribute |0 - 0| = 0
-            const float4 a = ok ? rq_re : zz, bq = ok ? rq_im : zz, c = ok ? rx_re : zz, e = ok ? rx_im : zz;
-            *reinterpret_cast<float4 *>(&sq[buf][2 * skq][srow * 4]) = make_float4(a.x, a.y, bq.x, bq.y);
-            *reinterpret_cast<float4 *>(&sq[buf][2 * skq + 1][srow * 4]) = make_float4(a.z, a.w, bq.z, bq.w);
-            *reinterpret_cast<float4 *>(&sx[buf][2 * skq][srow * 4]) = make_float4(c.x, c.y, e.x, e.y);
-            *reinterpret_cast<float4 *>(&sx[buf][2 * skq + 1][srow * 4]) = make_float4(c.z, c.w, e.z, e.w);
-        } else {
-            const bool ok0 = k0 + 4 * skq < k_hi, ok1 = k0 + 4 * skq + 2 < k_hi;
-            *reinterpret_cast<float4 *>(&sq[buf][2 * skq][srow * 4]) = ok0 ? rq_re : zz;
-            *reinterpret_cast<float4 *>(&sq[buf][2 * skq + 1][srow * 4]) = ok1 ? rq_im : zz;
-            *reinterpret_cast<float4 *>(&sx[buf][2 * skq][srow * 4]) = ok0 ? rx_re : zz;
-            *reinterpret_cast<float4 *>(&sx[buf][2 * skq + 1][srow * 4]) = ok1 ? rx_im : zz;
+#pragma unroll
+        for (int j = 0; j < kTileNQ; ++j) {
+            const int kq = k0 + 4 * (skq + 4 * j), g0 = 2 * (skq + 4 * j);
+            if constexpr (CP) {
+                const bool ok = kq < k_hi;  // dims past the split's range contribute |0 - 0| = 0
+                const float4 a = ok ? rq_re[j] : zz, bq = ok ? rq_im[j] : zz, c = ok ? rx_re[j] : zz, e = ok ? rx_im[j] : zz;
+                *reinterpret_cast<float4 *>(&sq[buf][g0][srow * 4]) = make_float4(a.x, a.y, bq.x, bq.y);
+                *reinterpret_cast<float4 *>(&sq[buf][g0 + 1][srow * 4]) = make_float4(a.z, a.w, bq.z, bq.w);
+                *reinterpret_cast<float4 *>(&sx[buf][g0][srow * 4]) = make_float4(c.x, c.y, e.x, e.y);
+                *reinterpret_cast<float4 *>(&sx[buf][g0 + 1][srow * 4]) = make_float4(c.z, c.w, e.z, e.w);
+            } else {
+                const bool ok0 = kq < k_hi, ok1 = kq + 2 < k_hi;
+                *reinterpret_cast<float4 *>(&sq[buf][g0][srow * 4]) = ok0 ? rq_re[j] : zz;
+                *reinterpret_cast<float4 *>(&sq[buf][g0 + 1][srow * 4]) = ok1 ? rq_im[j] : zz;
+                *reinterpret_cast<float4 *>(&sx[buf][g0][srow * 4]) = ok0 ? rx_re[j] : zz;
+                *reinterpret_cast<float4 *>(&sx[buf][g0 + 1][srow * 4]) = ok1 ? rx_im[j] : zz;
+            }
         }
     };
     f2 acc[4][4];
@@ -127,18 +144,46 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
     for (int k0 = k_lo; k0 < k_hi; k0 += kTileKC) {
         const bool more = k0 + kTileKC < k_hi;
         if (more) gload(k0 + kTileKC);  // the next chunk's global loads fly under this chunk's pair math
+        if constexpr (CP) {
 #pragma unroll 1
-        for (int kp = 0; kp < kTileKC / 2; ++kp) {
-            float4 q[4], x[4];
+            for (int kp = 0; kp < kTileKC / 2; ++kp) {
+                float4 q[4], x[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) q[a] = *reinterpret_cast<const float4 *>(&sq[buf][kp][(wr + lr + 8 * a) * 4]);
+                for (int a = 0; a < 4; ++a) q[a] = *reinterpret_cast<const float4 *>(&sq[buf][kp][(wr + lr + 8 * a) * 4]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = *reinterpret_cast<const float4 *>(&sx[buf][kp][(wp + lp + 8 * c) * 4]);
+                for (int c = 0; c < 4; ++c) x[c] = *reinterpret_cast<const float4 *>(&sx[buf][kp][(wp + lp + 8 * c) * 4]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[a][c] += tile_pair_term<MODEL, HEAD>(q[a], x[c]);
+                    for (int c = 0; c < 4; ++c)
+                        acc[a][c] += tile_pair_term<MODEL, HEAD>(q[a], x[c]);
+            }
+        } else {
+            // the real-valued term is ~100 VALU operations per group against the round trip of its eight LDS reads, with two
+            // waves per SIMD to hide it: the next group's operands are requested before this group's terms are evaluated
+            // (two register sets that take turns: written as "q = qn; qn = load(kp + 1)" the compiler folds the copy away
+            // and waits for the loads it has just issued)
+            float4 qa[4], xa[4], qb[4], xb[4];
+            auto lds_group = [&](int kp, float4 (&q)[4], float4 (&x)[4]) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) q[a] = *reinterpret_cast<const float4 *>(&sq[buf][kp][(wr + lr + 8 * a) * 4]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = *reinterpret_cast<const float4 *>(&sx[buf][kp][(wp + lp + 8 * c) * 4]);
+            };
+            auto terms = [&](const float4 (&q)[4], const float4 (&x)[4]) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] += tile_pair_term<MODEL, HEAD>(q[a], x[c]);
+            };
+            lds_group(0, qa, xa);
+#pragma unroll 1
+            for (int kp = 0; kp < kTileKC / 2; kp += 2) {
+                lds_group(kp + 1, qb, xb);
+                terms(qa, xa);
+                lds_group(min(kp + 2, kTileKC / 2 - 1), qa, xa);
+                terms(qb, xb);
+            }
         }
         if (more) lstore(buf ^ 1, k0 + kTileKC);
         __syncthreads();
@@ -184,7 +229,11 @@ static int launch_fwd_tile(const PoolLaunch &L, const PoolArgs &A0, hipStream_t 
         const bool fringe = A.P > T.Kd;
         T.fringe_tiles = fringe ? (A.B + TI - 1) / TI : 0;
         T.fringe_slices = fringe ? L.tile_fringe_slices : 0;
-        const size_t lds = fringe ? (size_t)3 * ((A.P - T.Kd + T.fringe_slices - 1) / T.fringe_slices) * 4 : 0;
+        if (const char *e = getenv("MKB_POOL_TILE_ONLY")) {  // measurement only (WRONG scores): 'd' = the dense tiles alone, 'f' = the fringe alone
+            if (e[0] == 'd') { T.fringe_tiles = 0; T.fringe_slices = 0; }
+            if (e[0] == 'f') T.pos_tiles = 0;
+        }
+        const size_t lds = (T.fringe_tiles > 0) ? (size_t)3 * ((A.P - T.Kd + T.fringe_slices - 1) / T.fringe_slices) * 4 : 0;
         const unsigned blocks = (unsigned)(T.fringe_tiles * T.fringe_slices + T.row_tiles * T.pos_tiles * T.ks);
         if (L.fkpt == 4) hipLaunchKernelGGL((pool_fwd_tile_kernel<MODEL, HEAD, 4>), dim3(blocks), dim3(256), lds, st, A, T);
         else hipLaunchKernelGGL((pool_fwd_tile_kernel<MODEL, HEAD, 2>), dim3(blocks), dim3(256), lds, st, A, T);
