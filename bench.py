@@ -519,7 +519,7 @@ def roofline_of(res, world, want_traffic):
     # (template arguments: model id, head-batch, units per lane, dense pass); the internal class name rides along as `class`
     mid = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}.get(MODEL, "?")
     guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else "mkb::gemm128_bf16x3_mfma_kernel<true, false, 0, ..> (dQ = G . X)"),
-             "pool_fwd": (f"mkb::pool_fwd_tile_kernel<{mid}, true|false, ..>" if MODEL == "RotatE" else f"mkb::pool_fwd_kernel<{mid}, ..>"),
+             "pool_fwd": (f"mkb::pool_fwd_tile_kernel<{mid}, true|false, ..>" if MODEL in ("RotatE", "TransE") and HIDDEN >= 300 else f"mkb::pool_fwd_kernel<{mid}, ..>"),
              "pool_bwd_x": "mkb::gemm128_bf16x3_mfma_kernel<false, false, 0, ..> (dX = G^T . Q)", "adam": "mkb::adam_rows_catchup_kernel"}.get(prof_kind, prof_kind)
     kernel_name = kname or guess
     info = ctx["sampler"].generate(ctx["train"][:Bk], "head-batch")._mkb_pool
@@ -551,7 +551,8 @@ def roofline_of(res, world, want_traffic):
     p_used = int(used.any(dim=0).sum().item())          # pool positions at least one row uses (P' of SURVEY 8d)
     units = m_.hidden_dim if MODEL == "RotatE" else De  # pair terms per (row, position)
     bwd = prof_kind != "pool_fwd"
-    per_term = {"RotatE": ((6, 1), (15, 1)), "TransE": ((2, 0), (4, 0)), "pRotatE": ((4, 1), (9, 2)),
+    # (TransE backward: z = q - x, then dq -= g sign(z), dx += g sign(z): one subtraction and two multiply-adds = 5 flop per term)
+    per_term = {"RotatE": ((6, 1), (15, 1)), "TransE": ((2, 0), (5, 0)), "pRotatE": ((4, 1), (9, 2)),
                 "ComplEx": ((2, 0), (4, 0)), "DistMult": ((2, 0), (4, 0))}[MODEL][1 if bwd else 0]
     mfma = MODEL in ("ComplEx", "DistMult")
     if mfma:  # S = Q.X^T | dQ = G.X | dX = G^T.Q over [B, P'] -- algorithmic: the columns somebody uses
@@ -583,8 +584,14 @@ def roofline_of(res, world, want_traffic):
         roof["issue_floor_us"] = floor_us
         roof["frac_of_issue_floor"] = floor_us / (avg_s * 1e6)
     if MODEL == "TransE":
-        roof["bound_note"] = ("2-4 flop per 4-byte pair term: the kernel is bound by moving operands (L2 -> registers, LDS "
-                              "read-modify-write of dx), not by the VALU; the fraction of the fp32 peak is reported for continuity only")
+        # issue floor at the measured rate of a plain fp32 VALU instruction (1.17 ns per wave64 instruction and SIMD): forward
+        # sub + |.|-add = 2 per term, backward sub + v_med3_i32 + v_cvt + 2 fma = 5 per term (model_math.h), on 1024 SIMDs
+        floor_us = float(pairs) * units / 64.0 / 1024.0 * (5 if bwd else 2) * 1.17 / 1e3
+        roof["issue_floor_us"] = floor_us
+        roof["frac_of_issue_floor"] = floor_us / (avg_s * 1e6)
+        roof["bound_note"] = ("2-5 VALU operations per 4-byte pair term: next to the pair math the kernel moves operands (LDS images of the "
+                              "candidate rows, the LDS read-modify-write of dx) and keeps its per-position books; the fraction of the "
+                              "fp32 peak counts the pair math alone")
     if trans:
         t_rate = trans / avg_s / 1e12
         roof.update({"transcendental_rate_Tops": t_rate, "transcendental_peak_Tops": TRANS_PEAK_TOPS,

@@ -48,7 +48,7 @@ timeout 300 python tools/pipeline_speed.py 2>&1 | tail -1 > $O/pipeline_speed.tx
 # the literal drop-in paths (README loop / Pipeline on the host dataset, torch.optim.Adam or mkb_amd.optim.Adam)
 timeout 900 python tools/dropin_paths.py 2>/dev/null | grep -E "^#|ms/step" > $O/dropin_paths.txt
 # one training step of the other configurations as kernel timelines
-for c in wn18rr-rotate umls-transe fb15k237-complex yago310-rotate; do tools/timeline.sh rf_$c $c > /dev/null 2>&1; mv gpurun_out/tl_rf_$c.txt $O/timeline_$c.txt; done
+for c in wn18rr-rotate umls-transe fb15k237-complex fb15k237-transe yago310-rotate; do tools/timeline.sh rf_$c $c > /dev/null 2>&1; mv gpurun_out/tl_rf_$c.txt $O/timeline_$c.txt; done
 # the row-sharded step through RCCL at world 1 (bench line + kernel trace with the rccl kernels)
 tools/rccl_world1.sh > $O/rccl_world1.log 2>&1; cp -r gpurun_out/rccl1 $O/rccl1
 rm -rf $O/ktrace $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_sq $O/pmc_clk   # keep the summaries, not the databases
