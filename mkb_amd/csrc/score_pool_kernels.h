@@ -824,6 +824,9 @@ __global__ __launch_bounds__(64) void pool_bwd_wave_kernel(PoolArgs A) {
 //   flush     = after the last phase the LDS array goes to the table gradient rows (one fp32 atomic per element and row
 //               group: 8 per element at the headline shape, as before); dq partial stored once per wave and block.
 // Nothing is recomputed: RotatE 9 packed ops + 2 v_rsq per two complex dims (the two-pass kernels: 14 + 4).
+#ifndef MKB_HANDON_PRIO
+#define MKB_HANDON_PRIO 0
+#endif
 constexpr int kBwd1Waves = 16;
 constexpr int kChunkStride = 1;                         // chunks (= phases) between a wave and the next wave of the chain
 constexpr int kChunks = kBwd1Waves * kChunkStride;      // chunks per block = phases per tile
@@ -963,6 +966,7 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
             // time (per-wave trace: half of every wave's loop time was hand-off wait) and a lone wave cannot fill the VALU.
             // A wave that is ahead of a SIMD mate (waves w, w+4, w+8, w+12 share a SIMD) drops to priority 0, the others
             // run at 3: the four stay within a phase of each other and interleave instruction by instruction.
+#if MKB_HANDON_PRIO == 0  // (A/B builds, tools/kbench.py: 1 = no priority changes at all, 2 = a static priority by wave age, set once)
             int behind = 0x3fffffff;
 #pragma unroll
             for (int k = 1; k < 4; ++k)
@@ -970,7 +974,13 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
                                                                                        __HIP_MEMORY_SCOPE_WORKGROUP)));
             if (finished > behind) __builtin_amdgcn_s_setprio(0);
             else __builtin_amdgcn_s_setprio(3);
+#endif
         };
+#if MKB_HANDON_PRIO == 2
+        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
         if constexpr (DENSE) {
             // Dense pass.  In phase ph the wave owns chunk (wave + ph) mod 16 = lanes l0, l0 + cph, ... of half h; the first
             // nd = dense_lanes / cph of them are dense positions.  All eight rows take the pair body unconditionally (a row that
