@@ -320,7 +320,21 @@ int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp
  * mkb_rows_comm_stats: plans made, takes that found their plan not executed yet, and how many of those found `stream` idle
  *   (only those are bubbles on the device: the others mean the host ran ahead of it). */
 #define MKB_ROWS_COMM_ID_BYTES 256
+#define MKB_ROWS_MAX_WORLD 64
 typedef struct mkb_rows_comm mkb_rows_comm_t;
+/* what a plan posts for the host (inside a communicator: host-coherent memory): seq is stored LAST, with system-scope release */
+typedef struct {
+    int64_t seq;
+    int64_t sent[MKB_ROWS_MAX_WORLD];    /* rows this rank asks each owner for (= the route's counts) */
+    int64_t wanted[MKB_ROWS_MAX_WORLD];  /* rows each rank asks this owner for                        */
+} mkb_rows_mailbox_t;
+/* The two kernels of mkb_rows_comm_plan on their own (a caller with a transport of its own moves the blocks between them; the
+ * tests play several ranks in one process with them).  blocks: [world][1 + cap] int64 -- pack writes block w = [counts[w] | the
+ * ids of owner w's group of send_ids]; unpack reads block j = what rank j asks this owner for, writes `want` (requester after
+ * requester), then mail->sent = counts, mail->wanted, and mail->seq = seq last.  mail: any device-visible memory. */
+int mkb_rows_blocks_pack(const int64_t *counts, const int64_t *send_ids, int64_t *blocks, int world, int64_t cap, void *stream);
+int mkb_rows_blocks_unpack(const int64_t *blocks, const int64_t *counts, int64_t *want, int64_t want_cap, mkb_rows_mailbox_t *mail,
+                           int64_t seq, int32_t *bad, int world, int64_t cap, void *stream);
 int mkb_rows_comm_available(void);
 int mkb_rows_comm_unique_id(uint8_t *id_host);
 int mkb_rows_comm_create(const uint8_t *id_host, int rank, int world, int64_t max_requests, mkb_rows_comm_t **out);

@@ -107,6 +107,8 @@ _SIGNATURES = {
                                 c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_scatter_add": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_void_p, c_int64,
                                      c_void_p, c_void_p, c_void_p]),
+    "mkb_rows_blocks_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "mkb_rows_blocks_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p]),
     "mkb_rows_comm_available": (c_int, []),
     "mkb_rows_comm_unique_id": (c_int, [c_void_p]),
     "mkb_rows_comm_create": (c_int, [c_void_p, c_int, c_int, c_int64, POINTER(c_void_p)]),

@@ -13,9 +13,12 @@
 //   mkb_rows_comm_take      reads the mailbox (plain loads: no HIP call, no event, no stream synchronisation; it spins only if
 //                           the plan has not executed yet, and counts how often it did so while the step's stream was idle)
 //                           and makes the step's stream wait for the plan;
-//   mkb_rows_comm_exchange  ONE ncclGroup on the step's stream: the packed all-reduce (pool rows + weight sum, or pool-row /
-//                           relation gradients + loss) and the all-to-all of the positive rows (ncclSend / ncclRecv per
-//                           peer, exact sizes from the mailbox: the row payload is never padded) -- called twice per step.
+//   mkb_rows_comm_exchange  on the step's stream: the packed all-reduce (pool rows + weight sum, or pool-row / relation
+//                           gradients + loss) and ONE ncclGroup with the all-to-all of the positive rows (ncclSend / ncclRecv
+//                           per peer, exact sizes from the mailbox: the row payload is never padded) -- called twice per step.
+//                           (World 1 and MKB_ROWS_ONE_GROUP=1: the all-reduce inside the same group.)
+// mkb_rows_blocks_pack / _unpack are the plan's two kernels on their own: for a caller with a transport of its own, and for the
+// test that plays several ranks in one process (tests/test_gpu_rows.py).
 //
 // RCCL is bound at run time (dlopen of the copy already in the process -- torch's -- or of the system's): libmkb_hip.so links
 // libamdhip64 only and loads on a box without RCCL; mkb_rows_comm_available() says whether this part can be used.
@@ -80,14 +83,10 @@ static RcclApi &rccl() {
     } while (0)
 
 constexpr int kCommSlots = 4;     // plans in flight (a plan lives from its plan() to the take() of its step)
-constexpr int kCommMaxWorld = 64;
+constexpr int kCommMaxWorld = MKB_ROWS_MAX_WORLD;
 static_assert(sizeof(ncclUniqueId) * 2 <= MKB_ROWS_COMM_ID_BYTES, "two unique ids must fit the id blob");
 
-struct Mailbox {  // host-coherent: written by the unpack kernel, read by mkb_rows_comm_take
-    int64_t seq;
-    int64_t sent[kCommMaxWorld];    // rows this rank asks each owner for (the route's counts)
-    int64_t wanted[kCommMaxWorld];  // rows each rank asks this owner for
-};
+typedef mkb_rows_mailbox_t Mailbox;  // host-coherent in a communicator: written by the unpack kernel, read by mkb_rows_comm_take
 
 struct PackArgs {
     const int64_t *counts, *send_ids;
@@ -168,6 +167,27 @@ struct mkb_rows_comm {
     int64_t plans = 0, waited = 0, waited_idle = 0;
 };
 
+// The two kernels of a plan on their own, for a caller that moves the blocks with a transport of its own (and for the tests, which
+// play several ranks in one process on one GPU: RCCL itself refuses two ranks on one device).
+extern "C" int mkb_rows_blocks_pack(const int64_t *counts, const int64_t *send_ids, int64_t *blocks, int world, int64_t cap, void *stream) {
+    MKB_REQUIRE(counts && send_ids && blocks, "null pointer");
+    MKB_REQUIRE(world >= 1 && world <= kCommMaxWorld && cap > 0 && cap <= (1 << 24), "bad world / capacity");
+    PackArgs P{counts, send_ids, blocks, world, (int)cap};
+    hipLaunchKernelGGL(rows_pack_kernel, dim3(world), dim3(256), 0, (hipStream_t)stream, P);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+extern "C" int mkb_rows_blocks_unpack(const int64_t *blocks, const int64_t *counts, int64_t *want, int64_t want_cap,
+                                      mkb_rows_mailbox_t *mail, int64_t seq, int32_t *bad, int world, int64_t cap, void *stream) {
+    MKB_REQUIRE(blocks && counts && want && mail, "null pointer");
+    MKB_REQUIRE(world >= 1 && world <= kCommMaxWorld && cap > 0 && cap <= (1 << 24) && want_cap >= 0, "bad world / capacity");
+    UnpackArgs U{blocks, counts, want, want_cap, mail, seq, bad, world, (int)cap};
+    hipLaunchKernelGGL(rows_unpack_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, U);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 extern "C" int mkb_rows_comm_available(void) { return rccl().ok ? 1 : 0; }
 
 extern "C" int mkb_rows_comm_unique_id(uint8_t *id_host) {
@@ -238,9 +258,7 @@ extern "C" int mkb_rows_comm_plan(mkb_rows_comm_t *c, int slot, const int64_t *s
         MKB_CHECK_HIP(hipStreamWaitEvent(side, c->after, 0));
     }
     if (int rc = mkb_rows_route(sample, b, 1, c->world, row0, send_ids, slot_of, counts, compact, bad, side_stream)) return rc;
-    PackArgs P{counts, send_ids, c->send_block[slot], c->world, (int)c->cap};
-    hipLaunchKernelGGL(rows_pack_kernel, dim3(c->world), dim3(256), 0, side, P);
-    MKB_LAUNCH_CHECK();
+    if (int rc = mkb_rows_blocks_pack(counts, send_ids, c->send_block[slot], c->world, c->cap, side_stream)) return rc;
     const size_t n = (size_t)(1 + c->cap);
     MKB_CHECK_NCCL(rccl().GroupStart());
     for (int p = 0; p < c->world; ++p) {
@@ -249,9 +267,8 @@ extern "C" int mkb_rows_comm_plan(mkb_rows_comm_t *c, int slot, const int64_t *s
     }
     MKB_CHECK_NCCL(rccl().GroupEnd());
     c->seq_of[slot] = ++c->plans;
-    UnpackArgs U{c->recv_block[slot], counts, want, want_cap, c->mail_dev + slot, c->seq_of[slot], bad, c->world, (int)c->cap};
-    hipLaunchKernelGGL(rows_unpack_kernel, dim3(1), dim3(1024), 0, side, U);
-    MKB_LAUNCH_CHECK();
+    if (int rc = mkb_rows_blocks_unpack(c->recv_block[slot], counts, want, want_cap, c->mail_dev + slot, c->seq_of[slot], bad, c->world,
+                                        c->cap, side_stream)) return rc;
     MKB_CHECK_HIP(hipEventRecord(c->ready[slot], side));
     return MKB_OK;
 }

@@ -115,3 +115,59 @@ def test_sharded_catch_up_is_the_plain_catch_up_on_the_materialised_list(defer):
         outs.append((p.detach().clone(), opt.state[p]["m"].clone(), opt.state[p]["v"].clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("world,b", [(2, 96), (3, 50), (8, 128), (8, 1024)])
+def test_plan_blocks_played_for_several_ranks_on_one_device(world, b):
+    """The device side of ``mkb_rows_comm_plan`` at world > 1.  RCCL refuses two ranks on one device and only 1-GPU boxes can be
+    reached, so the plan's transport cannot run here with several ranks -- but its two kernels can: every rank's route + pack is
+    played in this process, the blocks are handed over the way the send / receive group would (rank r receives block r of every
+    rank), and unpack must give every owner the right ``want`` list and both count vectors.  Then the rows travel the same way
+    (owners gather ``want``, requesters take their segments) and every request must come back with its row of the full table."""
+    import ctypes
+
+    from mkb_amd import _hip
+    from mkb_amd.table_rows import HipRowOps
+
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(100 * world + b)
+    N, D, cap = 5000, 12, 2 * b
+    full = torch.randn(N, D, generator=g).cuda()
+    ops = HipRowOps()
+    ranks = []
+    for r in range(world):
+        hubs = torch.randint(N, (5,), generator=g)
+        ent = torch.where(torch.rand(2 * b, generator=g) < 0.3, hubs[torch.randint(5, (2 * b,), generator=g)], torch.randint(N, (2 * b,), generator=g))
+        sample = torch.stack([ent[:b], torch.randint(7, (b,), generator=g), ent[b:]], 1).cuda()
+        send_ids, slot, counts, compact = ops.route(sample, world, 0, sample_layout=True)
+        blocks = torch.full((world, 1 + cap), -7, dtype=torch.int64, device="cuda")
+        _hip.check(lib.mkb_rows_blocks_pack(_hip.ptr(counts), _hip.ptr(send_ids), _hip.ptr(blocks), world, cap, _hip.stream_ptr()), "pack")
+        ranks.append(dict(sample=sample, send_ids=send_ids, slot=slot, counts=counts, blocks=blocks))
+    counts_all = torch.stack([x["counts"] for x in ranks]).cpu()  # [requester, owner]
+    for r, me in enumerate(ranks):
+        recv = torch.stack([ranks[j]["blocks"][r] for j in range(world)]).contiguous()  # what the group delivers to owner r
+        want = torch.full((world * cap,), -9, dtype=torch.int64, device="cuda")
+        mail = torch.zeros(1 + 2 * 64, dtype=torch.int64, device="cuda")
+        bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _hip.check(lib.mkb_rows_blocks_unpack(_hip.ptr(recv), _hip.ptr(me["counts"]), _hip.ptr(want), want.numel(), _hip.ptr(mail), 41 + r,
+                                             _hip.ptr(bad), world, cap, _hip.stream_ptr()), "unpack")
+        m = mail.cpu()
+        assert int(bad.item()) == 0 and int(m[0]) == 41 + r
+        assert torch.equal(m[1: 1 + world], counts_all[r]) and torch.equal(m[65: 65 + world], counts_all[:, r])
+        expect = []
+        for j in range(world):
+            lo = int(counts_all[j, :r].sum())
+            expect.append(ranks[j]["send_ids"][lo: lo + int(counts_all[j, r])])
+        expect = torch.cat(expect)
+        assert torch.equal(want[: expect.numel()], expect)
+        me["want"], me["wanted"] = want[: expect.numel()], counts_all[:, r]
+        # the owner reads what it was asked for (shard index s of rank r is entity s * world + r)
+        me["reply"] = full[me["want"] * world + r]
+    for j, me in enumerate(ranks):  # rows back to the requesters, owner after owner: the all-to-all of the step
+        got = []
+        for r in range(world):
+            lo = int(counts_all[:j, r].sum())
+            got.append(ranks[r]["reply"][lo: lo + int(counts_all[j, r])])
+        got = torch.cat(got)
+        ent = torch.cat([me["sample"][:, 0], me["sample"][:, 2]])
+        assert torch.equal(got[me["slot"].long()], full[ent])
