@@ -463,7 +463,10 @@ static bool pick_config(const mkb_tables_t *tb, int64_t B, int64_t P, PoolLaunch
             const char *e = getenv("MKB_POOL_DENSE");
             const int cph = 16 / L.pb_halves;
             const int ld = (int)((P / 2) / ((int64_t)npb * L.pb_halves)) / cph * cph;
-            const bool on = cp && (g_force_dense >= 0 ? g_force_dense == 1 : (e ? e[0] == '1' : true));  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
+            // (round 5: TransE as well -- with its pair term down to 5 VALU operations the general pass's per-position bookkeeping is a
+            // quarter of the loop: 62.7 -> 59.5 us at the headline shape, same call; DistMult / ComplEx / pRotatE never had the form)
+            const bool dense_model = cp || tb->model == MKB_TRANSE;
+            const bool on = dense_model && (g_force_dense >= 0 ? g_force_dense == 1 : (e ? e[0] == '1' : true));  // (launch_bwd1 compiles the dense form for the complex-modulus models only)
             if (on && cph >= 1 && ld > 0 && ld <= 32) L.dense_lanes = ld;
         }
         // Small problems: when the single-pass grid would be a handful of 16-wave workgroups, its ring and its prologue ARE the

@@ -1788,11 +1788,11 @@ static int launch_bwd1(const PoolLaunch &L, const PoolArgs &A, hipStream_t st) {
     A2.q_slices = L.q_slices; A2.dim_slices = L.dim_slices; A2.pb_halves = L.pb_halves; A2.tiles_per_wave = L.tiles_per_wave;
     A2.dense_lanes = A.g_blocked ? L.dense_lanes : 0;  // (the dense pass reads the blocked seed layout)
     A2.lds_ids_off = (int)(lds_main / 4);
-    // the dense form is compiled for the complex-modulus pair function only (plan_launch never asks for it elsewhere: measured
-    // slower for the real-valued models, and ten instantiations of this kernel are 0.6 MB of the library)
-    constexpr bool kHasDense = ModelTraits<MODEL>::cplx_pair;
+    // the dense form is compiled for the complex-modulus pair function and for TransE (pick_config never asks for it elsewhere:
+    // DistMult / ComplEx take the matrix route, pRotatE's term is two transcendental chains; every instantiation is ~60 KB)
+    constexpr bool kHasDense = ModelTraits<MODEL>::cplx_pair || MODEL == MKB_TRANSE;
     const bool dense = kHasDense && A2.dense_lanes > 0;
-    if (!kHasDense && A2.dense_lanes > 0) return set_error(MKB_ERR_INVALID, "the dense pass is built for complex-modulus models only");
+    if (!kHasDense && A2.dense_lanes > 0) return set_error(MKB_ERR_INVALID, "the dense pass is built for the complex-modulus models and TransE only");
     static LdsOptIn lds_ok[2];  // per instantiation: opt in to more than 64 KB of dynamic LDS once per device
     if (lds > 64 * 1024) {
         const void *fn = reinterpret_cast<const void *>(&pool_bwd1_kernel<MODEL, HEAD, KPT, false>);
