@@ -218,6 +218,11 @@ typedef struct {
     int64_t n;                                  /* elements */
     int64_t step;                               /* its own step count (>= 1) */
 } mkb_adam_dense_t;
+/* mkb_adam_step for up to 8 parameter tensors in ONE launch (each with its own step count): what an optimizer over a model's
+ * few dense tensors does per step -- small models are bound by launches, not by bytes (Umls TransE-64: 9 launches of ~5 us).
+ * draw_ahead: as in mkb_adam_rows_catchup (the sampler's next pool draw as one more workgroup of this launch), or null. */
+int mkb_adam_step_multi(const mkb_adam_dense_t *tensors_host, int n_tensors, float lr, float beta1, float beta2, float eps,
+                        int zero_grad, mkb_sampler_t *draw_ahead, void *stream);
 /* rider: null, or one dense tensor that takes its mkb_adam_step (with zero_grad) inside the same launch. */
 int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                        int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr, float beta1,

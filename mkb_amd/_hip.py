@@ -85,6 +85,7 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     "mkb_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_float, c_float,
                               c_float, c_int, c_void_p]),
+    "mkb_adam_step_multi": (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "mkb_profile_enable": (c_int, [c_int, c_int]),
     "mkb_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double)]),
     "mkb_adam_rows_catchup": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,

@@ -87,6 +87,64 @@ extern "C" int mkb_adam_step(float *param, float *grad, float *exp_avg, float *e
     return MKB_OK;
 }
 
+namespace mkb {
+constexpr int kAdamMulti = 8;
+struct AdamMultiArgs {
+    float *p[kAdamMulti], *g[kAdamMulti], *m[kAdamMulti], *v[kAdamMulti];
+    int64_t n[kAdamMulti];
+    float neg_step[kAdamMulti], sqrt_bc2[kAdamMulti];
+    int first_block[kAdamMulti + 1];  // tensor t owns blocks [first_block[t], first_block[t + 1])
+    int n_tensors, zero_grad;
+    float w1, b2, w2, eps;
+    int has_draw;  // the LAST block draws the negative sampler's next pool (pool_draw_body), as in the row-lazy launches
+    DrawArgs draw;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_multi_draw[];  // only sized when a draw block rides
+    if (A.has_draw && (int)blockIdx.x == A.first_block[A.n_tensors]) {
+        pool_draw_body<256>(A.draw, lds_multi_draw);
+        return;
+    }
+    int t = 0;
+    while (t + 1 < A.n_tensors && (int)blockIdx.x >= A.first_block[t + 1]) ++t;  // (workgroup-uniform)
+    const int64_t nb = A.first_block[t + 1] - A.first_block[t];
+    adam_dense_range(A.p[t], A.g[t], A.m[t], A.v[t], A.n[t], ((int64_t)blockIdx.x - A.first_block[t]) * 256 + threadIdx.x, nb * 256, A.w1,
+                     A.b2, A.w2, A.neg_step[t], A.sqrt_bc2[t], A.eps, A.zero_grad);
+}
+}  // namespace mkb
+
+extern "C" int mkb_adam_step_multi(const mkb_adam_dense_t *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+                                   int zero_grad, mkb_sampler_t *draw_ahead, void *stream) {
+    MKB_REQUIRE(tensors && n_tensors >= 1 && n_tensors <= mkb::kAdamMulti, "1..%d tensors", mkb::kAdamMulti);
+    mkb::AdamMultiArgs A{};
+    A.n_tensors = n_tensors; A.zero_grad = zero_grad; A.eps = eps; A.b2 = beta2;
+    A.w1 = (float)(1.0 - (double)beta1); A.w2 = (float)(1.0 - (double)beta2);
+    int blocks = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        const mkb_adam_dense_t &T = tensors[t];
+        MKB_REQUIRE(T.param && T.grad && T.exp_avg && T.exp_avg_sq && T.n >= 0 && T.step >= 1, "bad tensor %d", t);
+        MKB_REQUIRE((((uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq) & 15) == 0,
+                    "buffers must be 16-byte aligned");
+        A.p[t] = T.param; A.g[t] = T.grad; A.m[t] = T.exp_avg; A.v[t] = T.exp_avg_sq; A.n[t] = T.n;
+        const double bc1 = 1.0 - pow((double)beta1, (double)T.step), bc2 = 1.0 - pow((double)beta2, (double)T.step);
+        A.neg_step[t] = (float)(-((double)lr / bc1));  // (the same scalars, computed the same way, as mkb_adam_step: same bits)
+        A.sqrt_bc2[t] = (float)sqrt(bc2);
+        int64_t nb = ((T.n >> 2) + 255) / 256;
+        if (nb < 1) nb = 1;
+        if (nb > 2048) nb = 2048;
+        A.first_block[t] = blocks;
+        blocks += (int)nb;
+    }
+    A.first_block[n_tensors] = blocks;
+    size_t lds = 0;
+    if (draw_ahead && mkb::sampler_draw_ahead(draw_ahead, &A.draw, &lds)) { A.has_draw = 1; ++blocks; }
+    mkb::ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
+    hipLaunchKernelGGL(mkb::adam_multi_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, A);
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 // =====================================================================================================
 // Row-lazy dense Adam: identical arithmetic, HBM traffic proportional to the rows a step touches.
 //

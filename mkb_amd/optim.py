@@ -224,6 +224,7 @@ class Adam:
         self.step_count += 1
         lib = _hip.lib()
         rider_p, rider = self._rider()
+        dense_todo = []
         for p in self.params:
             if p.grad is None:
                 continue
@@ -273,9 +274,26 @@ class Adam:
                         st.pop("last"), st.pop("consts")
                         _links.detach(p)
                     st["n"] += 1
-                    _hip.check(lib.mkb_adam_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
-                                                 p.numel(), st["n"], self.lr, self.betas[0], self.betas[1], self.eps, 1,
-                                                 _hip.stream_ptr()), "mkb_adam_step")
+                    dense_todo.append((p, g, st))
+        # the dense tensors of a device step in ONE launch (mkb_adam_step_multi: the same arithmetic per element; small models
+        # are bound by launches -- Umls TransE-64 spends 9 launches of ~5 us per step)
+        while dense_todo:
+            dev = dense_todo[0][0].device
+            group = [t for t in dense_todo if t[0].device == dev][:8]
+            dense_todo = [t for t in dense_todo if not any(t is u for u in group)]
+            aligned = all(x.data_ptr() % 16 == 0 for p, g, st in group for x in (p.data, g, st["m"], st["v"]))
+            sampler = self._sampler_handle(dev)  # (its next pool is drawn by one more workgroup of this launch)
+            with _hip.on_device(dev):
+                if (len(group) > 1 or sampler is not None) and aligned:
+                    arr = (_hip.AdamDense * len(group))(*[_hip.AdamDense(p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(),
+                                                                          p.numel(), st["n"]) for p, g, st in group])
+                    _hip.check(lib.mkb_adam_step_multi(arr, len(group), self.lr, self.betas[0], self.betas[1], self.eps, 1,
+                                                       sampler, _hip.stream_ptr()), "mkb_adam_step_multi")
+                else:
+                    for p, g, st in group:
+                        _hip.check(lib.mkb_adam_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
+                                                     p.numel(), st["n"], self.lr, self.betas[0], self.betas[1], self.eps, 1,
+                                                     _hip.stream_ptr()), "mkb_adam_step")
         self._zeroed = True
 
     def zero_grad(self, set_to_none=False):
