@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/_pmc.sh <tag> <config> "<counters>" [ENV=..]: one rocprofv3 --pmc pass over a short bench run, per-kernel means
+# tools/pmc_pass.sh <tag> <config> "<counters>" [ENV=..]: one rocprofv3 --pmc pass over a short bench run, per-kernel means
 tag=$1; cfg=$2; ctr=$3; shift 3
 R=$(pwd); O=$R/gpurun_out/pmc_$tag; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
