@@ -458,3 +458,65 @@ def test_out_of_range_ids_raise_index_error_like_index_select():
     m(good[:1], torch.tensor([[0, N - 1]]).cuda(), "head-batch")
     m.check_ids()
     torch.cuda.synchronize()
+
+
+def test_score_functions_of_one_backward_pass_share_their_dense_gradient_buffer(monkeypatch):
+    """README-style step (positive scores and negative scores from two ``model(...)`` calls, one ``loss.backward()``): the two
+    backward functions share ONE dense gradient buffer per table (mkb_amd/_gradshare.py: the second accumulates into the first
+    one's tensor and returns None to autograd).  The gradients must equal those of the unshared form (every function its own
+    zero-filled buffer, the autograd engine adds them), and a second backward pass must start from fresh buffers."""
+    from mkb_amd import _gradshare, datasets, losses, models, sampling
+
+    ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    s, w = train[:64].contiguous(), (torch.rand(64) + 0.1).cuda()
+    crit = losses.Adversarial(alpha=0.5)
+
+    def grads(shared, name):
+        torch.manual_seed(3)
+        m = getattr(models, name)(hidden_dim=20, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=4)
+        if not shared:
+            monkeypatch.setattr(_gradshare, "_task", None)
+        out = []
+        for mode in ("head-batch", "tail-batch"):  # two backward passes without zero_grad in between: .grad accumulates
+            neg = ns.generate(s, mode)
+            crit(m(s), m(s, neg, mode), w).backward()
+            out.append((m.entity_embedding.grad.clone(), m.relation_embedding.grad.clone()))
+        monkeypatch.undo()
+        return out
+
+    for name in ("RotatE", "TransE", "pRotatE"):
+        a, b = grads(True, name), grads(False, name)
+        for (ea, ra), (eb, rb) in zip(a, b):
+            np.testing.assert_allclose(ea.cpu().numpy(), eb.cpu().numpy(), rtol=0, atol=2e-7)
+            np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_multi_tensor_dense_adam_equals_one_launch_per_tensor_bit_for_bit():
+    """``mkb_adam_step_multi`` (the dense tensors of a step in one launch, each with its own step count) against
+    ``mkb_adam_step`` per tensor: the same scalars, the same element arithmetic, the same bits -- odd sizes included."""
+    import ctypes
+
+    from mkb_amd import _hip
+
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(7)
+    sizes, steps = [135 * 64, 49 * 64 + 3, 1, 5000 * 36], [3, 1, 7, 2]
+
+    def make():
+        return [[torch.randn(n, generator=torch.Generator().manual_seed(100 + i + 10 * k)).cuda() for k in range(4)] for i, n in enumerate(sizes)]
+
+    a, b = make(), make()
+    for (p, gr, m, v), n, st in zip(a, sizes, steps):
+        v.abs_()
+        _hip.check(lib.mkb_adam_step(_hip.ptr(p), _hip.ptr(gr), _hip.ptr(m), _hip.ptr(v), n, st, 1e-2, 0.9, 0.999, 1e-8, 1, _hip.stream_ptr()), "single")
+    for (p, gr, m, v) in b:
+        v.abs_()
+    arr = (_hip.AdamDense * len(b))(*[_hip.AdamDense(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, st)
+                                       for (p, gr, m, v), n, st in zip(b, sizes, steps)])
+    _hip.check(lib.mkb_adam_step_multi(arr, len(b), 1e-2, 0.9, 0.999, 1e-8, 1, None, _hip.stream_ptr()), "multi")
+    for ta, tb in zip(a, b):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+    assert not any(t[1].any().item() for t in b)  # zero_grad rode the launch
