@@ -386,7 +386,7 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
 
 // one row: LANES lanes x EPL elements per pass.  The first chunk is requested BEFORE the ownership exchange returns (a
 // global atomic round trip ahead of the row's HBM latency otherwise); lanes that turn out to have nothing to do drop it.
-template <int EPL>
+template <int EPL, int UNROLL>
 __device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t row, bool valid, int lane, int lanes, int *s_old,
                                                  bool ahead) {
     if (lane == 0 && valid) *s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
@@ -399,10 +399,15 @@ __device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t r
     if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
     for (int64_t k = k0; k < A.D; k += (int64_t)EPL * lanes) {
         if (!ahead || k != k0) replay_load<EPL>(A, row, k, c);
-        replay_finish<EPL>(A, row, k, old, A.step, c);
+        replay_finish<EPL, UNROLL>(A, row, k, old, A.step, c);
     }
 }
 
+// UNROLL: pending zero-gradient steps replayed side by side.  4 (kReplayUnroll) where rows wait many steps between visits (the
+// chains are serial: WN18RR ~16 steps on average, YAGO3-10 up to the sweep period); 1 where they wait a few (FB15k-237: 5.7):
+// the replay is then a small part of the block's life, and 70 instead of 106 VGPRs let a third block share the CU (round 5:
+// 39.8 -> 37.9 us for the headline's launch).  The arithmetic per element and step is the same function either way: same bits.
+template <int UNROLL>
 __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_draw[];  // only sized when a draw block rides
     if (A.g && A.step > 0 && blockIdx.x == 0 && threadIdx.x == 0)
@@ -444,8 +449,8 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
         else row = r;
     }
     if (row < 0) { valid = false; row = 0; }  // a negative id = "not a row of this table" (an entry another rank owns): skipped
-    if (A.vec4) replay_row_block<4>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
-    else replay_row_block<2>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
+    if (A.vec4) replay_row_block<4, UNROLL>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
+    else replay_row_block<2, UNROLL>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
 }
 
 // A flush (every row of the table, no id list, no riders) is a stream over the whole table: p, m, v of every row with pending
@@ -600,6 +605,12 @@ static int attach_rider(AdamRowArgs &A, const mkb_adam_dense_t *rider, float lr,
     return MKB_OK;
 }
 
+// mean gap between two visits of a row = table rows / rows a launch lists: short gaps take the lean replay (see the kernel)
+static bool short_gaps(const AdamRowArgs &A) {
+    if (const char *e = getenv("MKB_ADAM_UNROLL")) return atoi(e) == 1;  // A/B switch (read per call)
+    return A.n_table > 0 && A.n_batch_rows > 0 && (int64_t)A.n_table < (int64_t)12 * A.n_batch_rows;
+}
+
 static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                         int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step_upto, float lr, float beta1,
                         float beta2, float eps, const mkb_adam_dense_t *rider, mkb_sampler_t *draw_ahead, void *stream,
@@ -631,8 +642,12 @@ static int rows_advance(float *param, float *grad, float *exp_avg, float *exp_av
     size_t lds = 0;
     if (draw_ahead && (ids || own_ids) && sampler_draw_ahead(draw_ahead, &A.draw, &lds)) A.first_row_block = 1;
     ProfScope ps(MKB_PROF_ADAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(n + extra + A.first_row_block)), dim3(kCatchThreads), lds,
-                       (hipStream_t)stream, A);
+    if (short_gaps(A))
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<1>, dim3((unsigned)(n + extra + A.first_row_block)), dim3(kCatchThreads), lds,
+                           (hipStream_t)stream, A);
+    else
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<kReplayUnroll>, dim3((unsigned)(n + extra + A.first_row_block)), dim3(kCatchThreads),
+                           lds, (hipStream_t)stream, A);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -666,9 +681,15 @@ static int rows_advance_generate(float *param, float *grad, float *exp_avg, floa
     const int64_t rows = A.n_ids;
     int64_t extra = 0;
     if (int rc = attach_rider(A, rider, lr, beta1, beta2, kCatchThreads, &extra)) return rc;
-    static LdsOptIn big_lds;  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once per device (160 KB per CU)
-    if (int rc = big_lds.ensure(reinterpret_cast<const void *>(&adam_rows_catchup_kernel), 96 * 1024)) return rc;
-    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3((unsigned)(1 + A.n_filter + rows + extra)), dim3(kCatchThreads), lds, st, A);
+    static LdsOptIn big_lds[2];  // 16 rows per filter workgroup need ~73 KB of dynamic LDS: opt in once per device (160 KB per CU)
+    const dim3 grid((unsigned)(1 + A.n_filter + rows + extra));
+    if (short_gaps(A)) {
+        if (int rc = big_lds[0].ensure(reinterpret_cast<const void *>(&adam_rows_catchup_kernel<1>), 96 * 1024)) return rc;
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<1>, grid, dim3(kCatchThreads), lds, st, A);
+    } else {
+        if (int rc = big_lds[1].ensure(reinterpret_cast<const void *>(&adam_rows_catchup_kernel<kReplayUnroll>), 96 * 1024)) return rc;
+        hipLaunchKernelGGL(adam_rows_catchup_kernel<kReplayUnroll>, grid, dim3(kCatchThreads), lds, st, A);
+    }
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
