@@ -406,7 +406,7 @@ __device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t r
 // UNROLL: pending zero-gradient steps replayed side by side.  4 (kReplayUnroll) where rows wait many steps between visits (the
 // chains are serial: WN18RR ~16 steps on average, YAGO3-10 up to the sweep period); 1 where they wait a few (FB15k-237: 5.7):
 // the replay is then a small part of the block's life, and 70 instead of 106 VGPRs let a third block share the CU (round 5:
-// 39.8 -> 37.9 us for the headline's launch).  The arithmetic per element and step is the same function either way: same bits.
+// 39.6 -> 37.6 us for the headline's launch; squeezed to 63 VGPRs for a fourth block it spills: 49 us).  The arithmetic per element and step is the same function either way: same bits.
 template <int UNROLL>
 __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRowArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_draw[];  // only sized when a draw block rides
