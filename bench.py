@@ -518,7 +518,11 @@ def roofline_of(res, world, want_traffic):
     # the rocprofv3 name of the class's kernel: taken from the PMC pass when there was one, else spelled from the configuration
     # (template arguments: model id, head-batch, units per lane, dense pass); the internal class name rides along as `class`
     mid = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}.get(MODEL, "?")
-    guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else "mkb::gemm128_bf16x3_mfma_kernel<true, false, 0, ..> (dQ = G . X)"),
+    paired = (MODEL in ("ComplEx", "DistMult") and os.environ.get("MKB_GEMM_NO_PAIR") is None and os.environ.get("MKB_GEMM_NO128") is None
+              and os.environ.get("MKB_GEMM_BF16X3", "1") != "0")  # the two backward products of the bilinear models in ONE launch (gemm_mfma.h)
+    guess = {"pool_bwd_q": (f"mkb::pool_bwd1_kernel<{mid}, true|false, .., ..>" if MODEL not in ("ComplEx", "DistMult") else
+                            ("mkb::gemm128_bf16x3_pair_kernel<true, false, 0, .., false, false, 0, ..> (dQ = G . X and dX = G^T . Q)" if paired
+                             else "mkb::gemm128_bf16x3_mfma_kernel<true, false, 0, ..> (dQ = G . X)")),
              "pool_fwd": (f"mkb::pool_fwd_tile_kernel<{mid}, true|false, ..>" if MODEL in ("RotatE", "TransE") and HIDDEN >= 300 else f"mkb::pool_fwd_kernel<{mid}, ..>"),
              "pool_bwd_x": "mkb::gemm128_bf16x3_mfma_kernel<false, false, 0, ..> (dX = G^T . Q)", "adam": "mkb::adam_rows_catchup_kernel"}.get(prof_kind, prof_kind)
     kernel_name = kname or guess
@@ -557,6 +561,8 @@ def roofline_of(res, world, want_traffic):
     mfma = MODEL in ("ComplEx", "DistMult")
     if mfma:  # S = Q.X^T | dQ = G.X | dX = G^T.Q over [B, P'] -- algorithmic: the columns somebody uses
         flop, trans = 2.0 * Bk * p_used * De, 0.0
+        if paired and prof_kind == "pool_bwd_q":
+            flop *= 2.0  # (both backward products ride the launch that is timed)
     else:
         flop, trans = float(pairs) * units * per_term[0], float(pairs) * units * per_term[1]
     ach = flop / avg_s / 1e12
@@ -564,7 +570,8 @@ def roofline_of(res, world, want_traffic):
     roof = {"bound": "mfma" if mfma else "valu", "kernel": kernel_name, "class": prof_kind, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
             "avg_kernel_us": avg_s * 1e6, "launches": launches, "algorithmic_flop_per_launch": flop,
-            "note": (f"{label}: " + (f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}"
+            "note": (f"{label}: " + ((f"two MFMA GEMMs (dQ = G . X, dX = G^T . Q) in one launch, 2 * B * P' * De each with P' = {p_used} used pool positions of {2 * K}"
+                                      if paired and prof_kind == "pool_bwd_q" else f"MFMA GEMM 2 * B * P' * De with P' = {p_used} used pool positions of {2 * K}")
                                      if mfma else f"{pairs} used (row, pool position) pairs x {units} terms x {per_term[0]} flop")
                      + "; peak = fp32 vector / matrix rate of MI355X")}
     if mfma and os.environ.get("MKB_GEMM_BF16X3", "1") != "0":

@@ -437,15 +437,17 @@ struct Bf16Stage {
     }
 };
 
+// (the workgroup's tile (bx, by) and K split bz of nz come as arguments: the kernel below passes its block indices, the PAIR kernel
+// further down the indices of whichever of its two products the workgroup belongs to)
 template <bool A_MK, bool B_NK, int EPI, int TN>
-__global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
+__device__ __forceinline__ void gemm128_bf16x3_body(const GemmArgs &G, const int bx, const int by, const int bz, const int nz,
+                                                    unsigned char *lds_b) {
     constexpr int TM = 128, KC = 32, T = 256, NT = TN / 64;
     constexpr int PLANE_A = TM * kBfPitch, PLANE_B = TN * kBfPitch;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
     unsigned char *sA = lds_b, *sB = lds_b + 3 * PLANE_A;
     int *s_idx = reinterpret_cast<int *>(lds_b + 3 * (PLANE_A + PLANE_B));  // [kper_] row ids of the K range (B_KN with b_idx)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int m0 = bx * TM, n0 = by * TN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * (TN / 2);
     f32x16 acc[2][NT];
 #pragma unroll
@@ -454,11 +456,11 @@ __global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int kper_ = ((G.K + gridDim.z - 1) / gridDim.z + KC - 1) / KC * KC;
+    const int kper_ = ((G.K + nz - 1) / nz + KC - 1) / KC * KC;
     __shared__ int s_red[16];
     int k_cut;
     if (gemm_depth_cut(G, m0, TM, n0, s_red, k_cut)) return;  // (workgroup-uniform)
-    const int k_lo = blockIdx.z * kper_, k_hi = min(min(G.K, k_cut), k_lo + kper_);
+    const int k_lo = bz * kper_, k_hi = min(min(G.K, k_cut), k_lo + kper_);
     if constexpr (!B_NK) {
         if (G.b_idx) {
             // (padded to whole chunks with the last id: the loads of a partial chunk need no clamp)
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
         multiply();
         __syncthreads();
     }
-    float *Cz = G.C + (int64_t)blockIdx.z * G.M * G.ldc;  // partial buffer of this K split (z = 0: C itself)
+    float *Cz = G.C + (int64_t)bz * G.M * G.ldc;  // partial buffer of this K split (z = 0: C itself)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -564,11 +566,37 @@ __global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
                 if (m < G.M && n < G.N) {
                     const float v = acc[a][b][reg];
                     if constexpr (EPI == GEMM_STORE) Cz[(int64_t)m * G.ldc + n] = v;
-                    else if constexpr (EPI == GEMM_STORE_AFFINE) Cz[(int64_t)m * G.ldc + n] = (gridDim.z > 1) ? v : G.c0 + G.c1 * v;
+                    else if constexpr (EPI == GEMM_STORE_AFFINE) Cz[(int64_t)m * G.ldc + n] = (nz > 1) ? v : G.c0 + G.c1 * v;
                     else if (v != 0.f) atomicAdd(G.C + G.c_idx[m] * G.ldc + n, v);
                 }
             }
         }
+}
+
+template <bool A_MK, bool B_NK, int EPI, int TN>
+__global__ __launch_bounds__(256) void gemm128_bf16x3_mfma_kernel(GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_gemm_bf[];
+    gemm128_bf16x3_body<A_MK, B_NK, EPI, TN>(G, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, lds_gemm_bf);
+}
+
+// Two independent products in ONE launch (round 5): the backward of the bilinear models is dQ = G . X followed by dX = G^T . Q --
+// two ~20 us launches of ~256 four-wave workgroups each, i.e. ONE workgroup per CU whose matrix pipe idles while it stages a chunk,
+// and a kernel boundary + ramp between them.  As one grid with the two products' workgroups interleaved, every CU holds one of
+// each from the start and they fill each other's staging phases.  grid: 1-D; P1 / P2: (tiles in m, tiles in n, K splits).
+struct GemmPairGrid { int mx1, ny1, nz1, mx2, ny2, nz2; };
+template <bool A1, bool B1, int E1, int TN1, bool A2, bool B2, int E2, int TN2>
+__global__ __launch_bounds__(256) void gemm128_bf16x3_pair_kernel(GemmArgs G1, GemmArgs G2, GemmPairGrid P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_gemm_pair[];
+    const int n1 = P.mx1 * P.ny1 * P.nz1, n2 = P.mx2 * P.ny2 * P.nz2, both = 2 * min(n1, n2);
+    const int b = (int)blockIdx.x;
+    int which, idx;  // (workgroup-uniform)
+    if (b < both) { which = b & 1; idx = b >> 1; }
+    else { which = n1 > n2 ? 0 : 1; idx = b - both + min(n1, n2); }
+    if (which == 0) {
+        if (idx < n1) gemm128_bf16x3_body<A1, B1, E1, TN1>(G1, idx % P.mx1, (idx / P.mx1) % P.ny1, idx / (P.mx1 * P.ny1), P.nz1, lds_gemm_pair);
+    } else {
+        if (idx < n2) gemm128_bf16x3_body<A2, B2, E2, TN2>(G2, idx % P.mx2, (idx / P.mx2) % P.ny2, idx / (P.mx2 * P.ny2), P.nz2, lds_gemm_pair);
+    }
 }
 
 // out[i] = c0 + c1 * sum_z part[z][i]   (fixed order: deterministic)
@@ -716,6 +744,69 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
     }
     MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
+// The backward pair of the bilinear models as ONE launch (gemm128_bf16x3_pair_kernel): dQ = G . X (A k-contiguous, B gathered rows,
+// STORE into up to `slices_cap` dQ slices) and the scattered dX = G^T . Q (through split-K partials, its tail -- one atomic per
+// element -- described in *x_tail or launched).  Plans each product exactly as launch_gemm would (tile width, K split); *done =
+// false when either does not qualify for the 128-row bf16 tiles (the caller then launches them one by one).
+static int launch_gemm_bwd_pair(GemmArgs GQ, int slices_cap, int *slices_used, GemmArgs GX, float *partials, GemmTail *x_tail,
+                                hipStream_t st, bool *done) {
+    *done = false;
+    static const bool off = getenv("MKB_GEMM_NO128") != nullptr || getenv("MKB_GEMM_NO_PAIR") != nullptr;  // A/B switches
+    const char *bx = getenv("MKB_GEMM_BF16X3");
+    if (off || !(bx ? bx[0] == '1' : kGemmBf16x3Default) || !partials || !slices_used || slices_cap < 1) return MKB_OK;
+    struct Plan { bool ok, narrow; int ks, tn, mx, ny; size_t lds; };
+    auto plan = [&](const GemmArgs &G, bool a_mk, bool b_nk, int cap) {
+        Plan P{false, false, 1, 128, 0, 0, 0};
+        const bool al = (((uintptr_t)G.A | (uintptr_t)G.B) & 15) == 0 && G.lda % 4 == 0 && G.ldb % 4 == 0 && G.M % 4 == 0 && G.N % 4 == 0 &&
+                        G.K % 4 == 0;
+        const int tiles128 = ((G.M + 127) / 128) * ((G.N + 127) / 128);
+        const int64_t a_span = (a_mk ? (int64_t)G.M * G.lda : (int64_t)G.K * G.lda) * 4;
+        const int64_t b_rows = G.b_idx ? G.b_rows : (b_nk ? (int64_t)G.N : (int64_t)G.K);
+        const bool fits32 = a_span < ((int64_t)1 << 31) && b_rows > 0 && b_rows * G.ldb * 4 < ((int64_t)1 << 31);
+        if (!al || tiles128 < 24 || !fits32) return P;
+        P.narrow = tiles128 < 200;
+        P.tn = P.narrow ? 64 : 128;
+        const int tiles = P.narrow ? ((G.M + 127) / 128) * ((G.N + 63) / 64) : tiles128;
+        static const int env_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 0;
+        const int min_wg = env_wg ? env_wg : 200;
+        while (tiles * P.ks < min_wg && P.ks < 8 && G.K / (P.ks * 2) >= 96 && (cap <= 0 || P.ks * 2 <= cap)) P.ks *= 2;
+        P.mx = (G.M + 127) / 128; P.ny = (G.N + P.tn - 1) / P.tn;
+        P.lds = (size_t)3 * (128 + P.tn) * kBfPitch + (size_t)(((G.K + P.ks - 1) / P.ks + 31) / 32 * 32) * 4;
+        P.ok = true;
+        return P;
+    };
+    const Plan pq = plan(GQ, true, false, slices_cap), px = plan(GX, false, false, 0);
+    if (!pq.ok || !px.ok) return MKB_OK;
+    GQ.ksplit = pq.ks;
+    *slices_used = pq.ks;
+    GemmArgs X2 = GX;  // partial products [ks, M, N], then one scattered add per element (the tail)
+    X2.C = partials; X2.ldc = GX.N; X2.ksplit = px.ks;
+    const GemmPairGrid grid{pq.mx, pq.ny, pq.ks, px.mx, px.ny, px.ks};
+    const size_t lds = pq.lds > px.lds ? pq.lds : px.lds;
+    const unsigned blocks = (unsigned)(pq.mx * pq.ny * pq.ks + px.mx * px.ny * px.ks);
+    auto go = [&](auto tq, auto tx) -> int {
+        constexpr int TQ = decltype(tq)::value, TX = decltype(tx)::value;
+        auto *fn = &gemm128_bf16x3_pair_kernel<true, false, GEMM_STORE, TQ, false, false, GEMM_STORE, TX>;
+        static LdsOptIn grant;  // (per instantiation of this generic lambda)
+        if (int rc = grant.ensure(reinterpret_cast<const void *>(fn), lds)) return rc;
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), lds, st, GQ, X2, grid);
+        return MKB_OK;
+    };
+    typedef std::integral_constant<int, 64> t64;
+    typedef std::integral_constant<int, 128> t128;
+    int rc;
+    if (pq.narrow) rc = px.narrow ? go(t64{}, t64{}) : go(t64{}, t128{});
+    else rc = px.narrow ? go(t128{}, t64{}) : go(t128{}, t128{});
+    if (rc) return rc;
+    const int *dp = GX.depth_mode == 3 ? GX.depth : nullptr;
+    if (x_tail) *x_tail = GemmTail{2, partials, GX.C, GX.c_idx, GX.M, GX.N, px.ks, GX.ldc, 0, 0.f, 1.f, dp, GX.n_depth};
+    else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)GX.M), dim3(256), 0, st, partials, GX.C, GX.c_idx, GX.M, GX.N, GX.ldc,
+                            px.ks, dp, GX.n_depth);
+    MKB_LAUNCH_CHECK();
+    *done = true;
     return MKB_OK;
 }
 

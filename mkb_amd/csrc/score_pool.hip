@@ -661,23 +661,30 @@ static int pooled_bwd(const mkb_tables_t *tb, bool head, const mkb_grads_t *gr, 
     static const bool no_cut = getenv("MKB_GEMM_NO_DEPTH") != nullptr;
     const bool cut = use_mfma(tb) && !no_cut;  // w.depth was written by this call's row_fwd / query_build
     if (use_mfma(tb)) {
-        {   // dQ [B, De] = G [B, P] . ent[pool]
-            GemmArgs g{};
-            g.A = w.G; g.lda = P; g.B = tb->ent; g.ldb = tb->entity_dim; g.b_idx = pool; g.b_rows = tb->n_entity;
-            g.C = w.dQ; g.ldc = tb->entity_dim; g.M = (int)B; g.N = (int)tb->entity_dim; g.K = (int)P;
-            if (cut) { g.depth = w.depth; g.depth_mode = 2; g.n_depth = (int)B; }  // (G is exactly 0 beyond a row's depth)
+        // dQ [B, De] = G [B, P] . ent[pool]
+        GemmArgs gq{};
+        gq.A = w.G; gq.lda = P; gq.B = tb->ent; gq.ldb = tb->entity_dim; gq.b_idx = pool; gq.b_rows = tb->n_entity;
+        gq.C = w.dQ; gq.ldc = tb->entity_dim; gq.M = (int)B; gq.N = (int)tb->entity_dim; gq.K = (int)P;
+        if (cut) { gq.depth = w.depth; gq.depth_mode = 2; gq.n_depth = (int)B; }  // (G is exactly 0 beyond a row's depth)
+        // g_ent[pool[p]] += (G^T [P, B] . Q [B, De])[p]
+        GemmArgs gx{};
+        gx.A = w.G; gx.lda = P; gx.B = w.Q; gx.ldb = tb->entity_dim; gx.b_idx = nullptr;
+        gx.C = gr->g_ent; gx.ldc = tb->entity_dim; gx.c_idx = pool; gx.M = (int)P; gx.N = (int)tb->entity_dim; gx.K = (int)B;
+        if (cut) { gx.depth = w.depth; gx.depth_mode = 3; gx.n_depth = (int)B; }
+        bool paired = false;
+        {   // round 5: both products in ONE launch where they qualify (profiled as the POOL_BWD_Q class)
             ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
-            // a K split of this product leaves its partials in the dQ slices: the row backward sums them (it does so for the
-            // VALU route's position blocks anyway) instead of a reduction launch in between (DistMult: 6.5 us)
-            if (int rc = launch_gemm<true, false, GEMM_STORE>(g, st, w.gemm_part, nullptr, 0, kMfmaDqSlices, &dq_used)) return rc;
+            if (int rc = launch_gemm_bwd_pair(gq, kMfmaDqSlices, &dq_used, gx, w.gemm_part, x_tail, st, &paired)) return rc;
         }
-        {   // g_ent[pool[p]] += (G^T [P, B] . Q [B, De])[p]
-            GemmArgs g{};
-            g.A = w.G; g.lda = P; g.B = w.Q; g.ldb = tb->entity_dim; g.b_idx = nullptr;
-            g.C = gr->g_ent; g.ldc = tb->entity_dim; g.c_idx = pool; g.M = (int)P; g.N = (int)tb->entity_dim; g.K = (int)B;
-            if (cut) { g.depth = w.depth; g.depth_mode = 3; g.n_depth = (int)B; }
+        if (!paired) {
+            {
+                ProfScope ps(MKB_PROF_POOL_BWD_Q, st);
+                // a K split of this product leaves its partials in the dQ slices: the row backward sums them (it does so for the
+                // VALU route's position blocks anyway) instead of a reduction launch in between (DistMult: 6.5 us)
+                if (int rc = launch_gemm<true, false, GEMM_STORE>(gq, st, w.gemm_part, nullptr, 0, kMfmaDqSlices, &dq_used)) return rc;
+            }
             ProfScope ps(MKB_PROF_POOL_BWD_X, st);
-            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(g, st, w.gemm_part, x_tail, x_tail ? 500 : 0)) return rc;
+            if (int rc = launch_gemm<false, false, GEMM_ATOMIC_ROWS>(gx, st, w.gemm_part, x_tail, x_tail ? 500 : 0)) return rc;
         }
     } else {
         PoolArgs A = make_args(tb, pool, cnt, B, P, w, L);
