@@ -754,7 +754,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
 static int launch_gemm_bwd_pair(GemmArgs GQ, int slices_cap, int *slices_used, GemmArgs GX, float *partials, GemmTail *x_tail,
                                 hipStream_t st, bool *done) {
     *done = false;
-    static const bool off = getenv("MKB_GEMM_NO128") != nullptr || getenv("MKB_GEMM_NO_PAIR") != nullptr;  // A/B switches
+    const bool off = getenv("MKB_GEMM_NO128") != nullptr || getenv("MKB_GEMM_NO_PAIR") != nullptr;  // A/B switches (read per call: the tests flip them within one process)
     const char *bx = getenv("MKB_GEMM_BF16X3");
     if (off || !(bx ? bx[0] == '1' : kGemmBf16x3Default) || !partials || !slices_used || slices_cap < 1) return MKB_OK;
     struct Plan { bool ok, narrow; int ks, tn, mx, ny; size_t lds; };

@@ -170,3 +170,21 @@ def test_workspace_guard_notices_a_write_behind_the_workspace(monkeypatch):
         fused.check_workspace_guards()
     guard[5] = fused._GUARD_VALUE
     fused.check_workspace_guards()
+
+
+@pytest.mark.parametrize("name,hidden,B,K", [("ComplEx", 1000, 1024, 256), ("DistMult", 1000, 1024, 256), ("ComplEx", 1030, 1000, 256),
+                                             ("DistMult", 1500, 1020, 250), ("ComplEx", 500, 2048, 384)])
+def test_backward_products_in_one_launch_equal_two_launches(name, hidden, B, K, monkeypatch):
+    """Round 5: dQ = G . X and dX = G^T . Q of the bilinear models ride ONE launch with their workgroups interleaved
+    (gemm128_bf16x3_pair_kernel).  The same tile code computes the same tiles in the same order per element, so the gradients
+    must equal those of the two-launch form (MKB_GEMM_NO_PAIR=1, read per call) up to the order of the final atomics -- at the
+    headline shape and at the edge shapes of the staging code (partial chunks, partial tiles, depth cuts)."""
+    for mode in ("head-batch", "tail-batch"):
+        monkeypatch.delenv("MKB_GEMM_NO_PAIR", raising=False)
+        a = _grads(name, hidden, B, K, "1", mode)
+        monkeypatch.setenv("MKB_GEMM_NO_PAIR", "1")
+        b = _grads(name, hidden, B, K, "1", mode)
+        monkeypatch.delenv("MKB_GEMM_NO_PAIR", raising=False)
+        assert abs(a[0] - b[0]) <= 1e-6 * max(1.0, abs(b[0]))
+        np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1e-6 * np.abs(b[1]).max())
+        np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-6 * np.abs(b[2]).max())
