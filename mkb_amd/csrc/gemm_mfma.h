@@ -771,7 +771,9 @@ static int launch_gemm_bwd_pair(GemmArgs GQ, int slices_cap, int *slices_used, G
         P.tn = P.narrow ? 64 : 128;
         const int tiles = P.narrow ? ((G.M + 127) / 128) * ((G.N + 63) / 64) : tiles128;
         static const int env_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 0;
-        const int min_wg = env_wg ? env_wg : 200;
+        // (short rows -- DistMult's 1000 floats -- leave few tiles: split K further there: 26.5 -> 23.4 us for its pair; the
+        // 2000-float rows of ComplEx lose with more splits, 42 -> 49 us: their partials are what the extra workgroups move)
+        const int min_wg = env_wg ? env_wg : (G.N <= 1024 ? 400 : 200);
         while (tiles * P.ks < min_wg && P.ks < 8 && G.K / (P.ks * 2) >= 96 && (cap <= 0 || P.ks * 2 <= cap)) P.ks *= 2;
         P.mx = (G.M + 127) / 128; P.ny = (G.N + P.tn - 1) / P.tn;
         P.lds = (size_t)3 * (128 + P.tn) * kBfPitch + (size_t)(((G.K + P.ks - 1) / P.ks + 31) / 32 * 32) * 4;
