@@ -229,7 +229,9 @@ static int launch_fwd_tile(const PoolLaunch &L, const PoolArgs &A0, hipStream_t 
         const bool fringe = A.P > T.Kd;
         T.fringe_tiles = fringe ? (A.B + TI - 1) / TI : 0;
         T.fringe_slices = fringe ? L.tile_fringe_slices : 0;
-        if (const char *e = getenv("MKB_POOL_TILE_ONLY")) {  // measurement only (WRONG scores): 'd' = the dense tiles alone, 'f' = the fringe alone
+        // measurement only, WRONG scores ('d' = the dense tiles alone, 'f' = the fringe alone): honoured only together with
+        // MKB_MEASURE_WRONG_RESULTS=1, so that a stray variable cannot silently break a run
+        if (const char *e = getenv("MKB_MEASURE_WRONG_RESULTS") ? getenv("MKB_POOL_TILE_ONLY") : nullptr) {
             if (e[0] == 'd') { T.fringe_tiles = 0; T.fringe_slices = 0; }
             if (e[0] == 'f') T.pos_tiles = 0;
         }
