@@ -261,7 +261,8 @@ int mkb_adam_rows_advance_generate(float *param, float *grad, float *exp_avg, fl
  *   the block; scatter: skipped).  local_ids (gather, optional out [n]): the shard index of each entry, or -1.
  * mkb_rows_gather: rows[j] = shard[ids[j]] for up to 4 segments in one launch; riders of the same launch: weight_sum[0] =
  *   sum of weight [n_weight] (fixed-order tree; null = none) and clearing `zero` (zero_bytes, whole floats, 16-byte aligned; 0 = none).
- * mkb_rows_scatter_add: grad[ids[j]] += rows[j] (fp32 atomics: duplicates add); rider: dense_dst [dense_n] += dense_src.
+ * mkb_rows_scatter_add: grad[ids[j]] += rows[j] (fp32 atomics: duplicates add); riders: dense_dst [dense_n] += dense_src,
+ *   copy_dst [copy_n <= 256] = copy_src (how the step's loss leaves the reused step buffers without a launch of its own).
  * occ (optional, [n_local] uint32, zero-initialised ONCE by the caller): the gather launch counts how often each shard row
  *   is listed in its segments; the scatter launch of the SAME segments adds rows listed once without atomics and resets the
  *   counts.  null = always atomics.
@@ -281,7 +282,8 @@ int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, const mkb_ro
                     const float *weight, int64_t n_weight, float *weight_sum, void *zero, int64_t zero_bytes, uint32_t *occ,
                     int32_t *bad, void *stream);
 int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs, float *dense_dst,
-                         const float *dense_src, int64_t dense_n, uint32_t *occ, int32_t *bad, void *stream);
+                         const float *dense_src, int64_t dense_n, float *copy_dst, const float *copy_src, int64_t copy_n,
+                         uint32_t *occ, int32_t *bad, void *stream);
 /* mkb_adam_rows_advance (grad != null) / mkb_adam_rows_catchup (grad == null) for a shard of such a table: the rows to visit
  * are global_ids [n_global] (entries other ranks own are skipped) followed by local_ids [n_local_ids] (shard indices).
  * Negative entries of any id list of the row-lazy calls are skipped. */

@@ -107,7 +107,7 @@ _SIGNATURES = {
     "mkb_rows_gather": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_scatter_add": (c_int, [c_void_p, c_int64, c_int64, POINTER(RowSeg), c_int, c_void_p, c_void_p, c_int64,
-                                     c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_blocks_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "mkb_rows_blocks_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int64, c_void_p]),
     "mkb_rows_comm_available": (c_int, []),

@@ -144,6 +144,7 @@ struct RowMoveArgs {
     const float *weight; int n_weight; float *weight_sum;   // gather: sum of the batch's weights (fixed-order tree)
     float4 *zero; int64_t zero_vec4; int zero_tail;         // gather: clear a scratch buffer (the compact gradient)
     float *dense_dst; const float *dense_src; int64_t dense_n;  // scatter: dense_dst += dense_src (the relation gradient)
+    float *copy_dst; const float *copy_src; int copy_n;         // scatter: copy_dst = copy_src (the loss leaves the ring buffers)
     int rider_blocks;
     // Exclusive rows.  occ[r] = how often shard row r is listed in this step's segments: counted by the gather launch (one
     // fire-and-forget atomic per listed row), read AND reset to 0 by the scatter launch of the same segments.  A row listed
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(kRowThreads) void rows_scatter_add_kernel(RowMoveAr
         const int rb = (int)blockIdx.x - A.row_blocks;
         for (int64_t e = (int64_t)rb * kRowThreads + tid; e < A.dense_n; e += (int64_t)A.rider_blocks * kRowThreads)
             A.dense_dst[e] += A.dense_src[e];
+        if (rb == 0 && tid < A.copy_n) A.copy_dst[tid] = A.copy_src[tid];
         return;
     }
     if (!locate(A, (int)blockIdx.x, s, j)) return;
@@ -340,18 +342,21 @@ extern "C" int mkb_rows_gather(const float *shard, int64_t n_local, int64_t D, c
 }
 
 extern "C" int mkb_rows_scatter_add(float *grad, int64_t n_local, int64_t D, const mkb_row_seg_t *segs, int n_segs,
-                                    float *dense_dst, const float *dense_src, int64_t dense_n, uint32_t *occ, int32_t *bad,
-                                    void *stream) {
+                                    float *dense_dst, const float *dense_src, int64_t dense_n, float *copy_dst,
+                                    const float *copy_src, int64_t copy_n, uint32_t *occ, int32_t *bad, void *stream) {
     MKB_REQUIRE(grad && n_local > 0 && D > 0, "bad gradient shard");
     MKB_REQUIRE(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "bad dense rider");
+    MKB_REQUIRE(copy_n >= 0 && copy_n <= kRowThreads && (copy_n == 0 || (copy_dst && copy_src)), "bad copy rider");
     RowMoveArgs A{};
     A.shard = grad;
     A.D = D; A.n_local = n_local; A.bad = bad;
     if (int rc = fill_segs(A, segs, n_segs, D, true)) return rc;
     A.dense_dst = dense_dst; A.dense_src = dense_src; A.dense_n = dense_n;
+    A.copy_dst = copy_dst; A.copy_src = copy_src; A.copy_n = (int)copy_n;
     A.occ = occ;
     int64_t rb = (dense_n + 4 * kRowThreads - 1) / (4 * kRowThreads);
     if (rb > 256) rb = 256;
+    if (rb == 0 && copy_n > 0) rb = 1;
     A.rider_blocks = (int)rb;
     if (A.row_blocks + A.rider_blocks == 0) return MKB_OK;
     hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)(A.row_blocks + A.rider_blocks)), dim3(kRowThreads), 0,

@@ -224,12 +224,13 @@ class HipRowOps:
                 _hip.stream_ptr()),
                 "mkb_rows_gather")
 
-    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
+    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None, copy_dst=None, copy_src=None):
         _hip.require_device(grad)
         with _hip.on_device(grad.device):
             _hip.check(_hip.lib().mkb_rows_scatter_add(
                 _hip.ptr(grad), grad.shape[0], grad.shape[1], self._segs(segs), len(segs), _hip.ptr(dense_dst),
-                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(occ), _hip.ptr(self._flag(grad.device)),
+                _hip.ptr(dense_src), 0 if dense_src is None else dense_src.numel(), _hip.ptr(copy_dst), _hip.ptr(copy_src),
+                0 if copy_src is None else copy_src.numel(), _hip.ptr(occ), _hip.ptr(self._flag(grad.device)),
                 _hip.stream_ptr()),
                 "mkb_rows_scatter_add")
 
@@ -695,8 +696,10 @@ class TableRowShardedStep:
                 if w is not None:
                     w.wait()
         # 5. owners add what they hold; the relation gradient joins relation.grad in the same launch
+        #    and the loss leaves the step buffers (the next step clears them) as a rider of that launch too
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
         ops.scatter_add(tb._grad(), [(info.pool, grad[:P], self.world, tb.rank, None), (want, back, 0, 0, None)],
-                        dense_dst=rel.grad, dense_src=bufs["g_rel"], occ=self._occ)
+                        dense_dst=rel.grad, dense_src=bufs["g_rel"], occ=self._occ, copy_dst=loss, copy_src=bufs["loss"])
         if self._trains_modulus and self.compute is None:
             mod = self._modulus
             if mod.grad is None:
@@ -704,7 +707,7 @@ class TableRowShardedStep:
             mod.grad.add_(bufs["g_mod"].view_as(mod.grad))
         if opt is not None:
             _links.mark_touched(tb.data, touched)
-        return bufs["loss"].clone().reshape(())
+        return loss.reshape(())
 
     def check(self):
         """Raise the reference's ``IndexError`` for ids outside the table that reached the row kernels since the last call (they

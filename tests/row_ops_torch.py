@@ -50,7 +50,9 @@ class TorchRowOps:
         if zero is not None:
             zero.zero_()
 
-    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None):
+    def scatter_add(self, grad, segs, dense_dst=None, dense_src=None, occ=None, copy_dst=None, copy_src=None):
+        if copy_src is not None:
+            copy_dst.copy_(copy_src)
         for seg in segs:
             idx, mine = self._rows(seg)
             grad.index_add_(0, idx[mine], seg[1][mine])
