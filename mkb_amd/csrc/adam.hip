@@ -261,7 +261,7 @@ struct RowChunk {
 };
 
 template <int EPL>
-__device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int64_t k, RowChunk<EPL> &c) {
+__device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, int k, RowChunk<EPL> &c) {
     const float *p = A.p + row * A.D + k, *m = A.m + row * A.D + k, *v = A.v + row * A.D + k;
     const float *g = A.g ? A.g + row * A.D + k : nullptr;
 #pragma unroll
@@ -296,9 +296,19 @@ __device__ __forceinline__ void replay_load(const AdamRowArgs &A, int64_t row, i
     }
 }
 
+// consts[s] for a wave-uniform s, read through the SCALAR cache (constant address space: s_load_dwordx2).  As an ordinary global
+// read the compiler has to assume the table changes under the launch (block 0 records consts[A.step], which is never read
+// back here: replay_consts) and issues a vector load plus s_waitcnt vmcnt(0) per replayed step -- an L1 / L2 round trip in every
+// link of the serial chain (round 5, ISA of the unroll-1 loop: two of them per step).
+__device__ __forceinline__ float2 consts_at(const AdamRowArgs &A, int s) {
+    typedef const float __attribute__((address_space(4))) *cptr;
+    cptr t = (cptr)(uintptr_t)(A.consts + s);
+    return make_float2(t[0], t[1]);
+}
+
 __device__ __forceinline__ float2 replay_consts(const AdamRowArgs &A, int s) {
     // advance form: consts[A.step] is being written by this very launch -- take it from the arguments
-    return (A.g && s == A.step) ? make_float2(A.neg_step, A.sqrt_bc2) : A.consts[s];
+    return (A.g && s == A.step) ? make_float2(A.neg_step, A.sqrt_bc2) : consts_at(A, s);
 }
 
 // replay the steps (from, to] of one chunk: the first with the row's gradient in the advance form, the rest with a zero
@@ -306,7 +316,7 @@ __device__ __forceinline__ float2 replay_consts(const AdamRowArgs &A, int s) {
 // the random pool ever touches), so the chain is kept short: half a workgroup (512 lanes x float4) or a whole one
 // (1024 lanes x float2) per row.
 template <int EPL, int UNROLL = kReplayUnroll>
-__device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int64_t k, int from, int to, RowChunk<EPL> &c) {
+__device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row, int k, int from, int to, RowChunk<EPL> &c) {
     f2 p[EPL / 2], m[EPL / 2], v[EPL / 2];
 #pragma unroll
     for (int e = 0; e < EPL / 2; ++e) {
@@ -314,7 +324,13 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
     }
     int s = from + 1;
     bool clear = false;
-    if (A.g) {  // the row's first pending step is the one its gradient row belongs to
+#if defined(MKB_ADAM_MEASURE) && (MKB_ADAM_MEASURE & 1)  // (measurement builds, WRONG results: rows move, nothing is replayed)
+    s = to + 1;
+    if (false)
+#else
+    if (A.g)
+#endif
+    {  // the row's first pending step is the one its gradient row belongs to
         const float2 cs = replay_consts(A, s);
         const float inv = __builtin_amdgcn_rcpf(cs.y);
 #pragma unroll
@@ -334,7 +350,7 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
     if (s + UNROLL - 1 <= last_tab) {
         float2 nx[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) nx[u] = A.consts[s + u];
+        for (int u = 0; u < UNROLL; ++u) nx[u] = consts_at(A, s + u);
         for (;;) {
             float2 cs[UNROLL];
 #pragma unroll
@@ -343,7 +359,7 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
             const bool more = s + UNROLL - 1 <= last_tab;
             if (more) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) nx[u] = A.consts[s + u];
+                for (int u = 0; u < UNROLL; ++u) nx[u] = consts_at(A, s + u);
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
@@ -389,15 +405,23 @@ __device__ __forceinline__ void replay_finish(const AdamRowArgs &A, int64_t row,
 template <int EPL, int UNROLL>
 __device__ __forceinline__ void replay_row_block(const AdamRowArgs &A, int64_t row, bool valid, int lane, int lanes, int *s_old,
                                                  bool ahead) {
+    // whole waves per row: the row index is wave-uniform -- say so, and the four row addresses become one scalar base each plus a
+    // 32-bit lane offset instead of four 64-bit vector addresses (registers: the point is a fourth workgroup per CU)
+    row = ((int64_t)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)row);
+    valid = __builtin_amdgcn_readfirstlane((int)valid) != 0;
+#if defined(MKB_ADAM_MEASURE) && (MKB_ADAM_MEASURE & 2)  // (measurement builds, WRONG results: no ownership exchange)
+    if (lane == 0 && valid) *s_old = A.step - 2;
+#else
     if (lane == 0 && valid) *s_old = atomicExch(&A.last[row], A.step);  // first claimant of a duplicated id does the work
-    const int64_t k0 = (int64_t)lane * EPL;
+#endif
+    const int k0 = lane * EPL, D = (int)A.D;  // (row lengths fit 31 bits: fill_args)
     RowChunk<EPL> c;
-    if (valid && ahead && k0 < A.D) replay_load<EPL>(A, row, k0, c);
+    if (valid && ahead && k0 < D) replay_load<EPL>(A, row, k0, c);
     __syncthreads();
     if (!valid) return;
     const int old = __builtin_amdgcn_readfirstlane(*s_old);  // (whole waves per row: uniform)
     if (old <= 0 || old >= A.step) return;  // never touched (m = v = 0: identity) or already current
-    for (int64_t k = k0; k < A.D; k += (int64_t)EPL * lanes) {
+    for (int k = k0; k < D; k += EPL * lanes) {
         if (!ahead || k != k0) replay_load<EPL>(A, row, k, c);
         replay_finish<EPL, UNROLL>(A, row, k, old, A.step, c);
     }
@@ -535,7 +559,7 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
 static int fill_args(AdamRowArgs &A, float *param, float *grad, float *m, float *v, int32_t *last, float *consts,
                      const int64_t *ids, int64_t D, int64_t step, float lr, float beta1, float beta2, float eps) {
     MKB_REQUIRE(param && m && v && last && consts, "null pointer");
-    MKB_REQUIRE(D > 0 && step >= 0 && step < INT32_MAX, "bad D / step");
+    MKB_REQUIRE(D > 0 && D < INT32_MAX && step >= 0 && step < INT32_MAX, "bad D / step");
     A.p = param; A.g = grad; A.m = m; A.v = v; A.last = last; A.consts = (float2 *)consts; A.ids = ids; A.D = D;
     A.step = (int32_t)step;
     A.w1 = (float)(1.0 - (double)beta1); A.b2 = beta2; A.w2 = (float)(1.0 - (double)beta2); A.eps = eps;

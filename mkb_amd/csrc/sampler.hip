@@ -269,6 +269,7 @@ int mkb::sampler_ride(mkb_sampler *s, const int64_t *sample, int64_t B, int mode
     if (int rc = take_pool(s, pool, st, &was_ahead)) return rc;
     // the carrier's blocks: one wave per row, as many rows per block as fit the carrier's 96 KB dynamic-LDS opt-in
     int rw = carrier_lanes / 64;
+    if (const char *e = getenv("MKB_FILTER_RW")) rw = std::max(1, std::min(rw, atoi(e)));  // A/B switch (read per call)
     while (rw > 1 && filter_lds_bytes(s->P(), s->P2(), rw) > (size_t)96 * 1024) --rw;
     *F = filter_args(s, sample, B, mode, neg, pos, cnt, touched, was_ahead ? pool : nullptr, rw);
     *pool_ids = F->pool;
