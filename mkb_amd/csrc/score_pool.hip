@@ -57,6 +57,28 @@ __global__ __launch_bounds__(256) void query_build_kernel(RowArgs A) {
     }
 }
 
+// sum of the slice partials of dQ for N elements of one row: the loads of four slices x N elements are requested together
+// and added in slice order.  (A plain loop over a run-time slice count waits for every load before it issues the next: the
+// ISA of row_bwd had 8 serial L2 round trips per lane and loop iteration there -- 32 per workgroup, most of the launch.)
+template <int N>
+__device__ __forceinline__ void dq_slices_sum(const float *__restrict__ dq, int64_t sstride, int nslices, const int (&k)[N], float (&out)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) out[e] = 0.f;
+    for (int s0 = 0; s0 < nslices; s0 += 4) {
+        float v[4][N];
+#pragma unroll
+        for (int z = 0; z < 4; ++z) {
+            const float *src = dq + (int64_t)min(s0 + z, nslices - 1) * sstride;
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[z][e] = src[k[e]];
+        }
+#pragma unroll
+        for (int z = 0; z < 4; ++z)
+#pragma unroll
+            for (int e = 0; e < N; ++e) out[e] += s0 + z < nslices ? v[z][e] : 0.f;
+    }
+}
+
 // chain dQ[i] (sum of the slice partials) into the fixed operands' gradient rows (duplicate rows add: atomics)
 template <int MODEL, bool HEAD>
 __global__ __launch_bounds__(256) void query_bwd_kernel(RowArgs A) {
@@ -67,17 +89,14 @@ __global__ __launch_bounds__(256) void query_bwd_kernel(RowArgs A) {
     const int64_t sstride = (int64_t)A.B * A.De;
     float *g_e = A.g_ent + (HEAD ? t : h) * A.De;
     float *g_r = A.g_rel + r * A.Dr;
-    auto dq_at = [&](int k) {
-        float s = 0.f;
-        for (int sl = 0; sl < A.nslices; ++sl) s += dq[sl * sstride + k];
-        return s;
-    };
     if constexpr (ModelTraits<MODEL>::cplx_query) {
         const float *e = HEAD ? et : eh;
         for (int u = threadIdx.x; u < A.d; u += 256) {
             Cplx de, dr;
+            float dqn[2];
+            dq_slices_sum<2>(dq, sstride, A.nslices, {u, A.d + u}, dqn);
             query_bwd_cplx<MODEL, HEAD>(Cplx{e[u], e[A.d + u]}, Cplx{er[u], MODEL == MKB_COMPLEX ? er[A.d + u] : 0.f},
-                                        Cplx{dq_at(u), dq_at(A.d + u)}, A.kd, de, dr);
+                                        Cplx{dqn[0], dqn[1]}, A.kd, de, dr);
             atomicAdd(g_e + u, de.re);
             atomicAdd(g_e + A.d + u, de.im);
             atomicAdd(g_r + u, dr.re);
@@ -85,8 +104,9 @@ __global__ __launch_bounds__(256) void query_bwd_kernel(RowArgs A) {
         }
     } else {
         for (int u = threadIdx.x; u < (int)A.De; u += 256) {
-            float da, db;
-            query_bwd_real<MODEL, HEAD>(HEAD ? er[u] : eh[u], HEAD ? et[u] : er[u], dq_at(u), A.kd, da, db);
+            float da, db, dqn[1];
+            dq_slices_sum<1>(dq, sstride, A.nslices, {u}, dqn);
+            query_bwd_real<MODEL, HEAD>(HEAD ? er[u] : eh[u], HEAD ? et[u] : er[u], dqn[0], A.kd, da, db);
             atomicAdd((HEAD ? g_r : g_e) + u, da);
             atomicAdd((HEAD ? g_e : g_r) + u, db);
         }
@@ -221,11 +241,6 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
     auto add_h = [&](int k, float v) { if (st_h) g_h[k] = v; else if (own_h) g_h[k] += v; else atomicAdd(g_h + k, v); };
     auto add_t = [&](int k, float v) { if (st_t) g_t[k] = v; else if (own_t) g_t[k] += v; else atomicAdd(g_t + k, v); };
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
-    auto dq_at = [&](int k) {
-        float s = 0.f;
-        for (int sl = 0; sl < A.nslices; ++sl) s += dq[sl * sstride + k];
-        return s;
-    };
     float extra = 0.f;
     if constexpr (ModelTraits<MODEL>::cplx_query) {
         for (int u = threadIdx.x; u < A.d; u += 256) {
@@ -244,7 +259,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
             Cplx dh, dr, dt = dxp, de, dr2;
             query_bwd_cplx<MODEL, false>(ch, cr, dqp, A.kd, dh, dr);
             // negative path: q = conj(rot) (x) t (head-batch) or h (x) rot (tail-batch)
-            const Cplx dqn{dq_at(u), dq_at(A.d + u)};
+            float dqs[2];
+            dq_slices_sum<2>(dq, sstride, A.nslices, {u, A.d + u}, dqs);
+            const Cplx dqn{dqs[0], dqs[1]};
             query_bwd_cplx<MODEL, HEAD>(HEAD ? ct : ch, cr, dqn, A.kd, de, dr2);
             if constexpr (HEAD) { dt.re += de.re; dt.im += de.im; } else { dh.re += de.re; dh.im += de.im; }
             dr.re += dr2.re; dr.im += dr2.im;
@@ -262,8 +279,9 @@ __global__ __launch_bounds__(256) void row_bwd_kernel(RowStepArgs A) {
             extra += gp * e0;
             float dh, dr, dt = dxp;
             query_bwd_real<MODEL, false>(vh, vr, dqp, A.kd, dh, dr);  // tail-style: a = h, b = r
-            float da, db;
-            query_bwd_real<MODEL, HEAD>(HEAD ? vr : vh, HEAD ? vt : vr, dq_at(u), A.kd, da, db);
+            float da, db, dqs[1];
+            dq_slices_sum<1>(dq, sstride, A.nslices, {u}, dqs);
+            query_bwd_real<MODEL, HEAD>(HEAD ? vr : vh, HEAD ? vt : vr, dqs[0], A.kd, da, db);
             if constexpr (HEAD) { dr += da; dt += db; } else { dh += da; dr += db; }
             add_h(u, dh);
             atomicAdd(g_r + u, dr);

@@ -1643,16 +1643,19 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
     const int h = sidx >> 6, l = sidx & 63;
     const int p = pb + R.npb * (l * R.halves + h);
     if (p >= R.P) return;
-    // which row groups used the slot: lane rg reads the mask of row group rg (all loads at once), a ballot collects them
-    unsigned long long used_rg = 0ull;
+    // which row groups used the slot: lane rg reads the mask of row group rg (all loads at once), ballots collect them
+    // (used_rg / used_rg2: row groups 0-63 / 64-127; `more`: somebody beyond those -- the plain loop at the bottom re-reads)
+    unsigned long long used_rg = 0ull, used_rg2 = 0ull;
+    bool more = false;
     for (int rg0 = 0; rg0 < R.row_groups; rg0 += 64) {
         const int rg = rg0 + (int)(threadIdx.x & 63);
         const bool u = rg < R.row_groups && ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull;
         const unsigned long long b = __ballot(u);
         if (rg0 == 0) used_rg = b;
-        else if (b) used_rg |= 1ull << 63;  // (more than 64 row groups: "somebody beyond the first 64"; the loops below re-read)
+        else if (rg0 == 64) used_rg2 = b;
+        else more |= b != 0ull;
     }
-    if (!used_rg) return;
+    if (!used_rg && !used_rg2 && !more) return;
     const int nc = R.kpt * (R.cplx ? 2 : 1), NU = R.cplx ? R.d : (int)R.De;
     const int64_t ent = R.pool[p];
     float *row = R.g_ent + ent * R.De;
@@ -1662,21 +1665,23 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
     const bool store = own && R.clear;
     auto add = [&](float *dst, float v) { if (store) *dst = v; else if (own) *dst += v; else atomicAdd(dst, v); };
     const int per_slot = R.dim_slices * 64 * nc;  // floats of one slot of one row group
-    if (nc == 4 && R.cplx) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
+    if (nc == 4 && R.cplx && R.row_groups <= 128) {  // RotatE with two complex dims per lane: 16-byte loads, [re0 re1 im0 im1] per lane
         for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
             const int u = e * 2;
             if (u >= NU) continue;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             // eight row groups at a time: their partial rows are requested together (a loop with a run-time trip count and a
-            // skip inside made every row group its own round trip), added in row-group order
+            // skip inside made every row group its own round trip), added in row-group order.  The "used" bits come from the two
+            // ballots above and from nowhere else: with a re-read of xused as the fallback for later row groups inside this
+            // loop, the compiler issued that load for EVERY row group and waited for it before the row's own load (round 5, ISA:
+            // sixteen serial round trips where one was meant)
             for (int rg0 = 0; rg0 < R.row_groups; rg0 += 8) {
                 float4 v[8];
                 bool on[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int rg = rg0 + k;
-                    on[k] = rg < R.row_groups && (rg < 63 ? ((used_rg >> rg) & 1ull) != 0ull
-                                                          : ((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull) != 0ull);
+                    on[k] = rg < R.row_groups && (((rg < 64 ? used_rg : used_rg2) >> (rg & 63)) & 1ull) != 0ull;
                     const int rgc = on[k] ? rg : 0;  // (row group 0's partial buffer always exists: a harmless address)
                     v[k] = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rgc * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
                 }
