@@ -29,9 +29,17 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
 }
 
 __device__ __forceinline__ float weight_sum_block(const float *__restrict__ w, int B, float *red) {
+    // four strides' loads at a time (a loop with a run-time trip count is one round trip per iteration: every workgroup of the
+    // loss launch walked 1024 weights in four of them); added in the order of the plain loop
     float acc = 0.f;
     if (threadIdx.x < 256)
-        for (int i = threadIdx.x; i < B; i += 256) acc += w[i];
+        for (int i0 = threadIdx.x; i0 < B; i0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) v[z] = w[min(i0 + 256 * z, B - 1)];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) acc += i0 + 256 * z < B ? v[z] : 0.f;
+        }
     return block_sum_256(acc, red);
 }
 
@@ -87,13 +95,15 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
             __syncthreads();
         }
     }
-    if (occ && (threadIdx.x & 63) == 0) {  // one lane per row: count the row's head and tail and its share of the pool ids
+    // one lane per row counts the row's head and tail and its share of the pool ids: the ids are requested here and used behind
+    // the row's own loads (requested, waited for and used up here they were one more round trip in front of everything else)
+    const bool occ_lane = occ && (threadIdx.x & 63) == 0 && (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6) < B;
+    int64_t occ_h = 0, occ_t = 0, occ_p = -1;
+    if (occ_lane) {
         const int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6);
-        if (row < B) {
-            atomicAdd(occ + occ_sample[3 * row], 1);
-            atomicAdd(occ + occ_sample[3 * row + 2], 1);
-            for (int64_t p = row; p < K; p += B) atomicAdd(occ + occ_pool[p], 1);
-        }
+        occ_h = occ_sample[3 * row];
+        occ_t = occ_sample[3 * row + 2];
+        if (row < K) occ_p = occ_pool[row];
     }
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int i_raw = blockIdx.x * RPB + r;
@@ -107,11 +117,16 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
         // scores still in split partials are reduced here, in the order of splitk_reduce_kernel (fixed: deterministic):
         //   kind 1: every column, part[z * n + i * K + j];  kind 3: columns < N (the forward tile's dense prefix), part[z][i][j]
         for (int t0 = 0; t0 < nt; t0 += 4) {
-            float cc[4], pz[4][8];
+            // (the multiplicities stay raw until the second loop: converted here, each group's uint16 load was waited for in
+            // front of the group's score loads -- the branch on `split` ends the basic block, and the wait with it: four round
+            // trips per batch of "four groups together", eight per 512-column row)
+            unsigned cu[4];
+            float pz[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {  // the loads of four column groups are issued together
                 const int t = t0 + u, j = lane + 64 * t, jc = min(j, K - 1);
-                cc[u] = crow ? (float)crow[jc] : 1.f;
+                cu[u] = 1u;
+                if (crow) cu[u] = crow[jc];
                 const bool split = NT.kind == 1 || (NT.kind == 3 && 64 * t < NT.N);  // (wave-uniform: N is a multiple of 64)
                 if (split) {
                     const float *pp = NT.kind == 1 ? NT.part + (int64_t)i * K + jc : NT.part + (int64_t)i * NT.N + min(j, NT.N - 1);
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
                 const int t = t0 + u, j = lane + 64 * t;
                 const bool ok = j < K;
                 const bool split = NT.kind == 1 || (NT.kind == 3 && 64 * t < NT.N);
-                const float c = ok ? cc[u] : 0.f;
+                const float c = ok ? (float)cu[u] : 0.f;
                 float v = pz[u][0];
                 if (split) {
                     float acc = 0.f;
@@ -148,6 +163,12 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
                 if (c > 0.f) m = fmaxf(m, alpha * v);
             }
         }
+    }
+    if (occ_lane) {
+        atomicAdd(occ + occ_h, 1);
+        atomicAdd(occ + occ_t, 1);
+        if (occ_p >= 0) atomicAdd(occ + occ_p, 1);
+        for (int64_t p = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6) + B; p < K; p += B) atomicAdd(occ + occ_pool[p], 1);
     }
     // scal == nullptr: W is reduced here, by every workgroup alike (its loads and barriers run under the row's loads, which
     // were issued above); workgroup 0 publishes it for the finish step
