@@ -28,6 +28,24 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// the same sum with its first four strides' loads already made by the caller (v[z] = w[min(tid + 256 z, B - 1)], lanes < 256):
+// the loss rows request them in front of their own loads
+__device__ __forceinline__ float weight_sum_block_ahead(const float *__restrict__ w, int B, float *red, const float (&v)[4]) {
+    float acc = 0.f;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) acc += (int)threadIdx.x + 256 * z < B ? v[z] : 0.f;
+        for (int i0 = threadIdx.x + 1024; i0 < B; i0 += 1024) {
+            float u[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) u[z] = w[min(i0 + 256 * z, B - 1)];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) acc += i0 + 256 * z < B ? u[z] : 0.f;
+        }
+    }
+    return block_sum_256(acc, red);
+}
+
 __device__ __forceinline__ float weight_sum_block(const float *__restrict__ w, int B, float *red) {
     // four strides' loads at a time (a loop with a run-time trip count is one round trip per iteration: every workgroup of the
     // loss launch walked 1024 weights in four of them); added in the order of the plain loop
@@ -109,6 +127,14 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     const int i_raw = blockIdx.x * RPB + r;
     const int i = min(i_raw, B - 1);  // (rows past the batch load row B-1 and leave after the workgroup-wide W reduction)
     const bool live = i_raw < B;
+    // everything else the row needs from global memory is requested here, in front of the row's own loads: the weights for W
+    // (scal == nullptr), the row's weight and positive score -- each was a round trip of its own further down
+    float wv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!scal && threadIdx.x < 256) {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) wv[z] = w[min((int)threadIdx.x + 256 * z, B - 1)];
+    }
+    const float wi = w[i], p_i = pos[i];
     const float *nrow = neg + (int64_t)i * K;
     const uint16_t *crow = cnt ? cnt + (int64_t)i * K : nullptr;
     const int nt = (K + 63) >> 6;
@@ -172,7 +198,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     }
     // scal == nullptr: W is reduced here, by every workgroup alike (its loads and barriers run under the row's loads, which
     // were issued above); workgroup 0 publishes it for the finish step
-    const float W = scal ? scal[0] : weight_sum_block(w, B, red);
+    const float W = scal ? scal[0] : weight_sum_block_ahead(w, B, red, wv);
     if (!scal && blockIdx.x == 0 && threadIdx.x == 0) scal_out[0] = W;
     if (!TILE && !live) return;
     if (live) {
@@ -209,7 +235,6 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
     }
     z = wave_sum(z);
     s = wave_sum(s);
-    const float wi = w[i];
     const float coef = 0.5f * wi / W;
     const float invz = 1.f / z;
     if (staged) {
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(TILE ? 512 : 256) void adversarial_rows_kernel(cons
         }
     }
     if (lane == 0) {
-        const float p = pos[i];
+        const float p = p_i;
         dpos[i] = -coef * fast_sigmoid(-p);
         rowpart[i] = wi * (fast_log_sigmoid(p) + s * invz);
     }
