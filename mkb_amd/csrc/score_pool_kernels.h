@@ -259,12 +259,18 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs &A, const int bx, c
     for (int base = 0; base < Pn; base += WG) {
         const int p = A.p_lo + sl + (base + tid) * nsl;
         unsigned m_own = 0;
+        int ent_p = 0;
         if (base + tid < Pn) {
+            // the eight multiplicities and the position's pool id are requested together, unconditionally (rows past the batch
+            // read row B - 1 and are masked): as conditional loads each sat in a basic block of its own and was waited for there --
+            // nine round trips per list pass (round 5, ISA), ten with the id fetched behind the compaction
             unsigned c[TI];
 #pragma unroll
-            for (int r = 0; r < TI; ++r) c[r] = (i0 + r < A.B) ? A.cnt[(int64_t)(i0 + r) * A.P + p] : 0;
+            for (int r = 0; r < TI; ++r) c[r] = A.cnt[(int64_t)min(i0 + r, A.B - 1) * A.P + p];
+            ent_p = (int)A.pool[p];
 #pragma unroll
             for (int r = 0; r < TI; ++r) {
+                if (i0 + r >= A.B) c[r] = 0;
                 m_own |= (c[r] != 0) ? (1u << r) : 0u;
                 // entries no row uses are defined as 0 (the pair loop below never visits them): no memset launch
                 if (c[r] == 0 && i0 + r < A.B) A.S[(int64_t)(i0 + r) * A.P + p] = 0.f;
@@ -275,7 +281,7 @@ __device__ __forceinline__ void pool_fwd_body(const PoolArgs &A, const int bx, c
         if (m_own != 0) {
             s_pos[slot] = p;
             s_mask[slot] = m_own;
-            s_row[slot] = (int)A.pool[p];
+            s_row[slot] = ent_p;
         }
         n_act += tot;
         __syncthreads();
