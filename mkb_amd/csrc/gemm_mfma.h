@@ -604,7 +604,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
                                                             int nz, float c0, float c1) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = 0.f;
-        for (int z = 0; z < nz; ++z) s += part[(int64_t)z * n + i];
+        for (int z0 = 0; z0 < nz; z0 += 8) {  // eight splits' loads at a time (one by one they are a round trip each), added in split order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)min(z0 + k, nz - 1) * n + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += z0 + k < nz ? v[k] : 0.f;
+        }
         out[i] = c0 + c1 * s;
     }
 }
@@ -618,9 +624,13 @@ __device__ __forceinline__ void splitk_scatter_block(const float *__restrict__ p
     float *row = out + c_idx[m] * ldc;
     for (int n = threadIdx.x * 4; n < N; n += 1024) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < nz; ++z) {
-            const float4 v = *reinterpret_cast<const float4 *>(part + ((int64_t)z * M + m) * N + n);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int z0 = 0; z0 < nz; z0 += 8) {  // eight splits' loads at a time, added in split order
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(part + ((int64_t)min(z0 + k, nz - 1) * M + m) * N + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (z0 + k < nz) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
         }
         if (a.x != 0.f) atomicAdd(row + n, a.x);
         if (a.y != 0.f) atomicAdd(row + n + 1, a.y);

@@ -1711,14 +1711,55 @@ __device__ __forceinline__ void pool_dx_reduce_block(const DxReduce &R, int bloc
         }
         return;
     }
+    if (nc == 4 && !R.cplx && R.row_groups <= 128 && (R.De & 3) == 0) {  // four real units per lane (TransE, hidden % 256 == 0 or not): 16-byte loads
+        for (int e = threadIdx.x; e < R.dim_slices * 64; e += 256) {
+            const int u = e * 4;
+            if (u >= NU) continue;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int rg0 = 0; rg0 < R.row_groups; rg0 += 8) {  // as above: eight row groups' partial rows together
+                float4 v[8];
+                bool on[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rg = rg0 + k;
+                    on[k] = rg < R.row_groups && (((rg < 64 ? used_rg : used_rg2) >> (rg & 63)) & 1ull) != 0ull;
+                    const int rgc = on[k] ? rg : 0;
+                    v[k] = *reinterpret_cast<const float4 *>(R.dXp + (((size_t)rgc * R.npb + pb) * cap + sidx) * per_slot + 4 * e);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (on[k]) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+            }
+            float4 *pr = reinterpret_cast<float4 *>(row + u);
+            if (store) *pr = a;
+            else if (own) { const float4 o = *pr; *pr = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w); }
+            else { atomicAdd(row + u, a.x); atomicAdd(row + u + 1, a.y); atomicAdd(row + u + 2, a.z); atomicAdd(row + u + 3, a.w); }
+        }
+        return;
+    }
     for (int f = threadIdx.x; f < per_slot; f += 256) {  // f = (dim slice * 64 + lane) * nc + component
         const int e = f / nc, c = f - e * nc;
         const int u = e * R.kpt + (c < R.kpt ? c : c - R.kpt);
         if (u >= NU) continue;
         float a = 0.f;
-        for (int rg = 0; rg < R.row_groups; ++rg) {
-            if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
-            a += R.dXp[(((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + f];
+        if (R.row_groups <= 128) {  // eight row groups' partials at a time, the "used" bits from the ballots above
+            for (int rg0 = 0; rg0 < R.row_groups; rg0 += 8) {
+                float v[8];
+                bool on[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rg = rg0 + k;
+                    on[k] = rg < R.row_groups && (((rg < 64 ? used_rg : used_rg2) >> (rg & 63)) & 1ull) != 0ull;
+                    v[k] = R.dXp[(((size_t)(on[k] ? rg : 0) * R.npb + pb) * cap + sidx) * per_slot + f];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += on[k] ? v[k] : 0.f;
+            }
+        } else {
+            for (int rg = 0; rg < R.row_groups; ++rg) {
+                if (!((R.xused[((size_t)rg * R.npb + pb) * 8 + h] >> l) & 1ull)) continue;
+                a += R.dXp[(((size_t)rg * R.npb + pb) * cap + sidx) * per_slot + f];
+            }
         }
         add(row + (c < R.kpt ? u : R.d + u), a);
     }

@@ -210,7 +210,13 @@ __global__ __launch_bounds__(256) void tile_scores_reduce_kernel(const float *__
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const int64_t i = e / Kd, p = e - i * Kd;
         float s = 0.f;
-        for (int z = 0; z < ks; ++z) s += part[(int64_t)z * n + e];
+        for (int z0 = 0; z0 < ks; z0 += 8) {  // eight splits' loads at a time, added in split order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(int64_t)min(z0 + k, ks - 1) * n + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += z0 + k < ks ? v[k] : 0.f;
+        }
         S[i * P + p] = cnt[i * P + p] ? c0 + c1 * s : 0.f;
     }
 }
