@@ -11,6 +11,8 @@ same parameter) accumulate their rows into that very tensor -- our kernels add i
 import torch
 from torch.utils.weak import WeakIdKeyDictionary
 
+from . import _links
+
 _task = getattr(torch._C, "_current_graph_task_id", None)
 _shared = WeakIdKeyDictionary()  # parameter -> (graph task id, buffer)
 
@@ -27,3 +29,24 @@ def take(param, tensor):
     buf = torch.zeros_like(tensor)
     _shared[param] = (tid, buf)
     return buf, True
+
+
+def direct(param, tensor, ids_fn):
+    """The table's own ``.grad`` when a row-lazy ``mkb_amd.optim.Adam`` steps it, else ``None``.  With such an optimizer the
+    backward functions add their rows STRAIGHT into ``param.grad`` (allocated by the optimizer, all-zero outside the rows that
+    are pending), record the rows (``ids_fn() -> int64 ids``, duplicates allowed) and hand autograd ``None`` for the table --
+    exactly what the fused step does.  Nothing dense is allocated, filled, added or stepped: the README loop
+    (``model(sample)`` / ``model(sample, negatives, mode)`` / ``loss.backward()`` / ``optimizer.step()``) keeps the row-lazy
+    route, where a dense buffer handed to autograd made the optimizer fall back to the dense kernel for good."""
+    if param is None or _links.owner(param) is None or not _links.owner(param).direct_grads:
+        return None
+    g = param.grad
+    if (g is None or tensor.data_ptr() != param.data_ptr() or g.shape != param.shape or not g.is_contiguous()
+            or g.dtype != torch.float32 or g.device != param.device):
+        return None
+    # (rows a forward pass of THIS optimizer step count made current -- models/base.py:_make_current -- need no second visit
+    # in front of the step launch)
+    st = _links.owner(param)._state(param)
+    _links.mark_touched(param, ids_fn(), current=st.get("fwd_n") == st["n"])
+    _links.rebase(param)
+    return g

@@ -83,7 +83,12 @@ class _PoolScoreFn(torch.autograd.Function):
         B, K = sample.shape[0], info.size
         G = torch.zeros((B, 2 * K), dtype=torch.float32, device=ent.device)
         G.scatter_add_(1, info.pos.long(), _hip.contiguous(dneg, torch.float32))
-        g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)  # (shared with the positive scores' backward of this pass)
+        # (a row-lazy optimizer's table takes its rows straight into .grad: _gradshare.direct)
+        g_ent = _gradshare.direct(model.entity_embedding, ent, lambda: info.touched if info.touched is not None
+                                  else torch.cat([info.pool, sample[:, 0::2].reshape(-1)]))
+        fresh_e = False
+        if g_ent is None:
+            g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)  # (shared with the positive scores' backward of this pass)
         g_rel, fresh_r = _gradshare.take(model.relation_embedding, rel)
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         gr = _hip.Grads(g_ent.data_ptr(), g_rel.data_ptr(), None if g_mod is None else g_mod.data_ptr())

@@ -59,7 +59,11 @@ class _ScoreFn(torch.autograd.Function):
         K = 1 if cand is None else cand.shape[1]
         dscore = _hip.contiguous(dscore, torch.float32)
         # (one dense buffer per table and backward pass: the positive and the negative score functions of a step share it)
-        g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)
+        # (a row-lazy optimizer's table takes its rows straight into .grad: _gradshare.direct)
+        g_ent = _gradshare.direct(model.entity_embedding, ent, lambda: _read_entity_ids(sample, cand)) if _few(cand) else None
+        fresh_e = False
+        if g_ent is None:
+            g_ent, fresh_e = _gradshare.take(model.entity_embedding, ent)
         g_rel, fresh_r = _gradshare.take(model.relation_embedding, rel)
         g_mod = torch.zeros_like(modulus) if model.name == "pRotatE" else None
         tb = model._tables(ent, rel, modulus)
@@ -70,6 +74,21 @@ class _ScoreFn(torch.autograd.Function):
             _hip.check(_hip.lib().mkb_score_bwd(tb, gr, _hip.ptr(sample), _hip.ptr(cand), B, K, ctx.mode,
                                                 _hip.ptr(dscore), _hip.ptr(ws), _hip.stream_ptr()), "mkb_score_bwd")
         return (g_ent if fresh_e else None), (g_rel if fresh_r else None), g_mod, None, None, None, None
+
+
+# candidate lists up to this many ids are made current row by row in front of a forward pass (and their gradient rows recorded
+# one by one behind the backward pass) when the table steps row-lazily; longer ones flush the table / take the dense gradient
+DIRECT_MAX_IDS = 16384
+
+
+def _few(cand):
+    return cand is None or cand.numel() <= DIRECT_MAX_IDS
+
+
+def _read_entity_ids(sample, cand=None):
+    """int64 ids of the entity rows a score of (sample, cand) reads: heads, tails (and the candidates)."""
+    ht = sample[:, 0::2].reshape(-1)
+    return ht if cand is None else torch.cat([ht, cand.reshape(-1)])
 
 
 class Base(nn.Module):
@@ -159,6 +178,26 @@ class BaseModel(Base):
             if opt is not None:
                 opt.flush(p)
 
+    def _make_current(self, sample, entity_ids):
+        """In front of a forward pass: the rows it reads are brought up to date when a row-lazy optimizer steps the tables
+        (``entity_ids``: int64 ids, duplicates allowed; ``None`` = too many to list: the whole table is flushed).  One small
+        launch per table with something pending -- the whole-table flush this replaces was 150 us per ``model(...)`` call at
+        the headline shape."""
+        for p, ids in ((self.entity_embedding, entity_ids), (self.relation_embedding, False)):
+            opt = _links.owner(p)
+            if opt is None:
+                continue
+            st = opt._state(p)
+            st["fwd_n"] = st["n"]  # (the rows read at this step count are current from here on: _gradshare.direct)
+            if st["n"] <= 0 or st.get("flushed") == st["n"]:
+                continue  # nothing pending
+            if ids is False:
+                ids = sample[:, 1]
+            if ids is None:
+                opt.flush(p)
+            else:
+                opt.catch_up(p, ids)
+
     # ------------------------------------------------------------------ reference API
     @property
     def embeddings(self):
@@ -191,7 +230,6 @@ class BaseModel(Base):
 
     def forward(self, sample, negative_sample=None, mode=None):
         _hip.require_device(self.entity_embedding, sample, negative_sample)
-        self.sync_parameters()
         sample, shape = self.format_sample(sample=sample, negative_sample=negative_sample)
         mode_id = _hip.mode_id(mode)
         sample = _hip.contiguous(sample, torch.int64)
@@ -205,6 +243,7 @@ class BaseModel(Base):
             return (self.entity_embedding.sum() * 0.0).expand(0, 1).reshape(shape)  # (differentiable: backward adds nothing)
         if VALIDATE_IDS:
             self._launch_id_check(sample, negative_sample if mode_id != _hip.MODE_DEFAULT else None)
+        lazy = _links.owner(self.entity_embedding) is not None or _links.owner(self.relation_embedding) is not None
         if mode_id != _hip.MODE_DEFAULT:
             pooled = getattr(negative_sample, "_mkb_pool", None)
             if (pooled is None and AUTO_POOL and negative_sample.dim() == 2 and negative_sample.shape[1] <= 512
@@ -213,8 +252,13 @@ class BaseModel(Base):
                 pooled = PoolInfo.discover(_hip.contiguous(negative_sample, torch.int64), sample, mode_id)
             if pooled is not None and pooled.usable_for(self, sample, mode_id):
                 from ..fused import pooled_forward
+                if lazy:
+                    self._make_current(sample, pooled.touched if pooled.touched is not None
+                                       else torch.cat([pooled.pool, _read_entity_ids(sample)]))
                 return pooled_forward(self, sample, pooled, mode_id).view(shape)
             cand = _hip.contiguous(negative_sample, torch.int64)
+        if lazy:
+            self._make_current(sample, _read_entity_ids(sample, cand) if _few(cand) else None)
         modulus = getattr(self, "modulus", None)
         if modulus is None:  # autograd.Function needs a tensor slot; never read by the kernels
             modulus = self.gamma

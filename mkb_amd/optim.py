@@ -46,10 +46,15 @@ class Adam:
         self.defer_step = defer_step  # None: off until compose.Pipeline (or the caller) turns it on; False: never
         self._pending_dense = None    # (parameter, AdamDense, lr, gradient tensor kept alive) of a deferred step
         self._zeroed = False
+        # the backward functions of model(...) add their rows straight into .grad of a row-lazily stepped table (no dense buffer
+        # goes through autograd: _gradshare.direct); False: they hand autograd a dense gradient as for any other optimizer
+        self.direct_grads = True
         if lazy_rows:
             for p in self.params:
                 if p.dim() == 2 and p.shape[0] >= 4096:  # big tables only; small ones stay on the dense kernel
                     _links.attach(p, self)
+                    if p.grad is None and p.is_cuda:
+                        p.grad = torch.zeros_like(p)  # (where the row gradients land; all-zero outside pending rows from now on)
 
     # ------------------------------------------------------------------ state
     def _state(self, p):
@@ -237,6 +242,7 @@ class Adam:
             if not g.is_contiguous():
                 g = p.grad = g.contiguous()
             wrote = _links.autograd_wrote(p)
+            current = _links.all_marks_current(p)  # (every row was made current by the forward pass that read it)
             touched = _links.take_touched(p) if _links.owner(p) is self else None
             if wrote:  # autograd accumulated into .grad in this step as well: which rows is unknown -> the dense route below
                 touched = None
@@ -262,7 +268,7 @@ class Adam:
                     st["n"] += 1
                     ids = _hip.contiguous(touched, torch.int64)
                     c = self._consts(st, st["n"])
-                    if done is None or done[0] is not touched or done[1] != st["n"] - 1:
+                    if not current and (done is None or done[0] is not touched or done[1] != st["n"] - 1):
                         self.catch_up(p, ids, upto=st["n"] - 1)  # e.g. rows only OTHER data-parallel ranks touched
                     _hip.check(lib.mkb_adam_rows_step(_hip.ptr(p.data), _hip.ptr(g), _hip.ptr(st["m"]), _hip.ptr(st["v"]),
                                                       _hip.ptr(st["last"]), _hip.ptr(c), p.shape[0], p.shape[1],

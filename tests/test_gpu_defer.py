@@ -325,3 +325,59 @@ def test_autograd_backward_before_a_fused_step_in_one_optimizer_step_is_not_over
     got = run(True)
     for x, y in zip(got, ref):
         assert torch.allclose(x, y, rtol=0, atol=5e-6), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("defer", [False, True])
+@pytest.mark.parametrize("name", ["RotatE", "TransE"])
+def test_readme_loop_keeps_the_row_lazy_route(name, defer):
+    """The reference's own loop (README.md:448-474: ``model(sample)``, ``model(sample, negatives, mode)``, ``loss.backward()``,
+    ``optimizer.step()``) with ``mkb_amd.optim.Adam(lazy_rows=True)``: the backward functions add their rows straight into
+    ``.grad`` of the row-lazily stepped table and record them (``_gradshare.direct``), the forward passes bring the rows they
+    read up to date -- no dense gradient goes through autograd, and the optimizer must STILL be on its row-lazy route at the
+    end (it used to fall back to the dense kernel after the first step).  Same tables as ``torch.optim.Adam`` on a twin."""
+    from mkb_amd import _links, losses, models, optim, sampling
+
+    N, R = 6000, 5
+    ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
+    rs = np.random.RandomState(2)
+    train = np.stack([rs.randint(N, size=4000), rs.randint(R, size=4000), rs.randint(N, size=4000)], 1)
+    t = torch.as_tensor(train).cuda()
+    w = torch.rand(64, device="cuda") + 0.5
+    crit = losses.Adversarial(alpha=0.5)
+
+    def run(fast):
+        torch.manual_seed(4)
+        m = getattr(models, name)(hidden_dim=24, entities=ents, relations=rels, gamma=6.0).cuda()
+        ns = sampling.NegativeSampling(size=32, train_triples=train, entities=ents, relations=rels, seed=3)
+        ps = [m.entity_embedding, m.relation_embedding]
+        opt = optim.Adam(ps, lr=1e-2, lazy_rows=True, defer_step=defer) if fast else torch.optim.Adam(ps, lr=1e-2)
+        seen = []
+        for it in range(9):
+            s = t[it * 64: (it + 1) * 64].contiguous()
+            mode = "head-batch" if it % 2 == 0 else "tail-batch"
+            opt.zero_grad()
+            pos = m(s)
+            neg = ns.generate(s, mode)
+            err = crit(pos, m(s, neg, mode), w)
+            err.backward()
+            if fast and it == 4:  # a second backward pass before one step (gradient accumulation)
+                crit(m(s), m(s, neg, mode), w).backward()
+            elif it == 4:
+                crit(m(s), m(s, neg, mode), w).backward()
+            opt.step()
+            seen.append(float(err.detach()))
+            if it == 6:  # evaluation in the middle: scores of triples the loop has not touched must see current rows
+                with torch.no_grad():
+                    seen.append(float(m(t[2000:2064].contiguous()).sum()))
+        if fast:
+            st = opt.state[m.entity_embedding]
+            assert "last" in st and _links.owner(m.entity_embedding) is opt, "the optimizer fell back to the dense kernel"
+            assert not _links.autograd_wrote(m.entity_embedding)
+            opt.flush()
+        return m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone(), seen
+
+    ref = run(False)
+    got = run(True)
+    assert np.allclose(got[2], ref[2], rtol=2e-5, atol=2e-5), (got[2], ref[2])
+    for x, y in zip(got[:2], ref[:2]):
+        assert torch.allclose(x, y, rtol=0, atol=2e-5), float((x - y).abs().max())

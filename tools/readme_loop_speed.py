@@ -1,15 +1,17 @@
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from mkb_amd import datasets, losses, models, optim, sampling
 ds = datasets.Fb15k237(batch_size=1024, shuffle=False, seed=42, num_workers=0)
 train = torch.as_tensor(ds.train, dtype=torch.int64).cuda()
 w = torch.ones(1024, device="cuda")
-for which in ("torch.optim.Adam", "mkb_amd.optim.Adam", "mkb_amd.optim.Adam(lazy_rows)"):
+for which in ("torch.optim.Adam", "mkb_amd.optim.Adam", "mkb_amd.optim.Adam(lazy_rows)", "mkb_amd.optim.Adam(lazy_rows, defer_step)", "mkb_amd.optim.Adam(lazy_rows, defer_step, draw_ahead)"):
+    if os.environ.get("MKB_README_ONLY") and os.environ["MKB_README_ONLY"] != which:
+        continue
     torch.manual_seed(42)
     m = models.RotatE(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9.0).cuda()
     ns = sampling.NegativeSampling(size=256, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=42)
     ps = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(ps, lr=5e-5) if which == "torch.optim.Adam" else optim.Adam(ps, lr=5e-5, lazy_rows="lazy" in which)
+    opt = torch.optim.Adam(ps, lr=5e-5) if which == "torch.optim.Adam" else optim.Adam(ps, lr=5e-5, lazy_rows="lazy" in which, defer_step=True if "defer" in which else None, draw_ahead=ns if "draw_ahead" in which else None)
     loss_fn = losses.Adversarial(alpha=1.0)
     def step(i):
         s = train[(i * 1024) % 200000: (i * 1024) % 200000 + 1024]
@@ -21,8 +23,8 @@ for which in ("torch.optim.Adam", "mkb_amd.optim.Adam", "mkb_amd.optim.Adam(lazy
         err.backward()
         opt.step()
         opt.zero_grad()
-    for i in range(5): step(i)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 40
-    for i in range(n): step(5 + i)
+    for i in range(30): step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
+    for i in range(n): step(30 + i)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"README loop, {which}: {dt*1e3:.3f} ms/step = {1024*257/dt/1e6:.0f} M triples/s")
