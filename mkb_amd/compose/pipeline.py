@@ -45,6 +45,34 @@ class _Patience:
         return self.stale == self.limit  # (limit 0 stops at the first evaluation, as the reference's == test does)
 
 
+class _HostStager:
+    """Host batch -> device without stopping the host: the batch is copied into one of ``depth`` page-locked buffers and sent
+    with a non-blocking copy on the current stream; an event per buffer says when it may be overwritten.  ``tensor.to(device)``
+    of a pageable tensor waits until the copy has RUN, i.e. until the device has finished everything queued before it -- the
+    host then prepares every step's launches with the device idle (the drop-in ``datasets`` loaders: 0.279 ms / step against
+    0.217 with batches resident on the device)."""
+
+    def __init__(self, device, depth=8):
+        self.device, self.depth, self.k, self.slots = device, depth, 0, {}
+
+    def __call__(self, t):
+        if not torch.is_tensor(t) or t.is_cuda or torch.device(self.device).type != "cuda":
+            return t.to(self.device)
+        key = (self.k % self.depth, t.dtype, tuple(t.shape))
+        self.k += 1
+        slot = self.slots.get(key)
+        if slot is None:
+            slot = self.slots[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
+        buf, ev = slot
+        if ev is not None:
+            ev.synchronize()  # (the copy that last read this buffer has run)
+        buf.copy_(t)
+        out = buf.to(self.device, non_blocking=True)
+        ev = slot[1] = torch.cuda.Event()
+        ev.record()
+        return out
+
+
 class Pipeline:
     def __init__(self, epochs, eval_every=2000, early_stopping_rounds=3, device="cpu"):
         self.epochs, self.eval_every, self.early_stopping_rounds = epochs, eval_every, early_stopping_rounds
@@ -97,12 +125,13 @@ class Pipeline:
         # model to the GPU still works); the explicit sequence follows the reference and uses self.device
         device = model.entity_embedding.device if fused is not None else self.device
         bar = Bar(dataset=dataset, update_every=10)
+        to_device = _HostStager(device) if fused is not None else (lambda t: t.to(device))
         for data in bar:
-            sample = data["sample"].to(device)
+            sample = to_device(data["sample"])
             mode = data["mode"]
             if mode == "classification":
                 raise NotImplementedError("classification mode (ConvE / BCE) is outside the mkb_amd hot path")
-            weight = data["weight"].to(device)
+            weight = to_device(data["weight"])
             if fused is not None:
                 # generate + fused step; with a row-lazy mkb_amd.optim.Adam the sampler rides the catch-up launch
                 error = fused.sampled(sample, weight, sampling, mode)
