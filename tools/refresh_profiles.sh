@@ -47,6 +47,8 @@ for w in 1 2 4 8; do timeout 300 python tools/shard_emulate.py $w 2>&1 | grep -v
 timeout 300 python tools/pipeline_speed.py 2>&1 | tail -1 > $O/pipeline_speed.txt
 # the literal drop-in paths (README loop / Pipeline on the host dataset, torch.optim.Adam or mkb_amd.optim.Adam)
 timeout 900 python tools/dropin_paths.py 2>/dev/null | grep -E "^#|ms/step" > $O/dropin_paths.txt
+echo "# tools/readme_loop_speed.py (README loop, batches sliced on the device, 300 timed steps; the row-lazy variants are host-bound)" >> $O/dropin_paths.txt
+timeout 600 python tools/readme_loop_speed.py 2>/dev/null | grep "README loop" >> $O/dropin_paths.txt
 # one training step of the other configurations as kernel timelines
 for c in wn18rr-rotate umls-transe fb15k237-complex fb15k237-transe yago310-rotate; do tools/timeline.sh rf_$c $c > /dev/null 2>&1; mv gpurun_out/tl_rf_$c.txt $O/timeline_$c.txt; done
 # the row-sharded step through RCCL at world 1 (bench line + kernel trace with the rccl kernels)
