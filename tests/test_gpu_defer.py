@@ -378,6 +378,10 @@ def test_readme_loop_keeps_the_row_lazy_route(name, defer):
 
     ref = run(False)
     got = run(True)
-    assert np.allclose(got[2], ref[2], rtol=2e-5, atol=2e-5), (got[2], ref[2])
+    # (both runs add gradient rows with fp32 atomics: where the contributions to an element nearly cancel, their order moves the
+    # Adam update of that element by a few per cent of lr -- seen: 5.1e-5 at lr 1e-2, in one process out of two.  A row that
+    # missed a step or was read stale is off by ~lr per step: two orders of magnitude above the bound.)
+    assert np.allclose(got[2], ref[2], rtol=1e-4, atol=1e-4), (got[2], ref[2])
     for x, y in zip(got[:2], ref[:2]):
-        assert torch.allclose(x, y, rtol=0, atol=2e-5), float((x - y).abs().max())
+        assert torch.allclose(x, y, rtol=0, atol=3e-4), float((x - y).abs().max())
+        assert float((x - y).abs().mean()) < 2e-6, float((x - y).abs().mean())
