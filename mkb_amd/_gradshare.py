@@ -9,12 +9,11 @@ same parameter) accumulate their rows into that very tensor -- our kernels add i
 ``None`` for it, which autograd takes as "no contribution".  Outside a backward pass (no graph task) nothing is shared.
 """
 import torch
-from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _links
 
 _task = getattr(torch._C, "_current_graph_task_id", None)
-_shared = WeakIdKeyDictionary()  # parameter -> (graph task id, buffer)
+_shared = _links.WeakIdTable()  # parameter -> (graph task id, buffer)
 
 
 def take(param, tensor):

@@ -6,19 +6,70 @@ They used to be attributes on the ``nn.Parameter``; torch pickles a Parameter's 
 ctypes sampler handle (which cannot be pickled at all) -- into the model file.  Identity-keyed weak tables keep the links
 out of the model: nothing here survives or travels with a parameter.
 """
+import weakref
+
 import torch
-from torch.utils.weak import WeakIdKeyDictionary
+
+
+class WeakIdTable:
+    """``parameter -> value``, keyed by identity, holding the parameter weakly.  (torch's ``WeakIdKeyDictionary`` does the
+    same through a wrapper object whose ``__eq__`` / ``__hash__`` run in Python: ~1.5 us per lookup, 15 lookups per training step
+    -- a tenth of the host's time per step at the small shapes.  Here: one ``dict.get(id(p))`` and one weak-reference call.)"""
+
+    def __init__(self):
+        self._d = {}
+
+    def _entry(self, p):
+        e = self._d.get(id(p))
+        return e if e is not None and e[0]() is p else None
+
+    def get(self, p, default=None):
+        e = self._entry(p)
+        return default if e is None else e[1]
+
+    def __contains__(self, p):
+        return self._entry(p) is not None
+
+    def __getitem__(self, p):
+        e = self._entry(p)
+        if e is None:
+            raise KeyError(p)
+        return e[1]
+
+    def __setitem__(self, p, value):
+        e = self._entry(p)
+        if e is not None:
+            e[1] = value
+            return
+        key, d = id(p), self._d
+
+        def gone(ref, key=key, d=d):
+            cur = d.get(key)
+            if cur is not None and cur[0] is ref:
+                del d[key]
+
+        d[key] = [weakref.ref(p, gone), value]
+
+    def pop(self, p, default=None):
+        e = self._entry(p)
+        if e is None:
+            return default
+        del self._d[id(p)]
+        return e[1]
+
+    def __len__(self):
+        return len(self._d)
 
 __all__ = ["all_marks_current", "attach", "autograd_wrote", "clear_autograd_wrote", "detach", "mark_touched", "owner", "rebase", "take_touched", "touched"]
 
-_owner = WeakIdKeyDictionary()    # parameter -> optimizer that defers its zero-gradient row steps
-_touched = WeakIdKeyDictionary()  # parameter -> int64 ids of the rows written since the optimizer last stepped
-_hooks = WeakIdKeyDictionary()    # parameter -> handle of the post-accumulate hook below
-_wrote = WeakIdKeyDictionary()    # parameter -> True once AUTOGRAD has accumulated into .grad since the optimizer last stepped
+_owner = WeakIdTable()    # parameter -> optimizer that defers its zero-gradient row steps
+_touched = WeakIdTable()  # parameter -> int64 ids of the rows written since the optimizer last stepped
+_hooks = WeakIdTable()    # parameter -> handle of the post-accumulate hook below
+_wrote = WeakIdTable()    # parameter -> True once AUTOGRAD has accumulated into .grad since the optimizer last stepped
 
 
-_marks = WeakIdKeyDictionary()    # parameter -> [mark_touched calls, those of them whose rows a forward pass had made current] since the last step
-_base = WeakIdKeyDictionary()     # parameter -> (data_ptr, version) of .grad when our own backward functions last looked at it
+_marks = WeakIdTable()    # parameter -> [mark_touched calls, those of them whose rows a forward pass had made current] since the last step
+_base = WeakIdTable()     # parameter -> (data_ptr, version) of .grad when our own backward functions last looked at it
 
 
 def _sig(p):
