@@ -155,3 +155,36 @@ def test_in_process_train_loaders_yield_the_worker_process_order():
     assert len(a) == len(b) > 0
     for (ma, sa, wa), (mb, sb, wb) in zip(a, b):
         assert ma == mb and torch.equal(sa, sb) and torch.equal(wa, wb)
+
+
+def test_row_lazy_replay_loop_has_no_vector_memory_load(tmp_path):
+    """Round 5: the per-step constants of the row-lazy Adam replay were ordinary global reads -- the compiler issued a vector load
+    and a full ``s_waitcnt vmcnt(0)`` per replayed step (two L2 round trips in every link of a serial chain; 5 us of the headline
+    step).  They go through the constant address space now (``s_load``).  This compiles adam.hip for gfx950 (device side only, a
+    few seconds, no GPU) and looks at the ISA: the replay loops -- the loops of ``adam_rows_catchup_kernel`` with ``v_sqrt_f32``
+    and no store -- must not hold a vector-memory load, and must read their constants with scalar loads."""
+    import importlib.util
+    import pathlib
+    import subprocess
+
+    from mkb_amd.csrc import build as hb
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("isa_chains", root / "tools" / "isa_chains.py")
+    ic = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ic)
+    asm = tmp_path / "adam.s"
+    subprocess.run([hb.HIPCC, *hb.FLAGS, "-I", str(root / "include"), "--cuda-device-only", "-S",
+                    str(root / "mkb_amd" / "csrc" / "adam.hip"), "-o", str(asm)], check=True, capture_output=True)
+    seen = 0
+    for name, body in ic.kernels(asm).items():
+        if "adam_rows_catchup_kernel" not in name:
+            continue
+        replay = [ls for ls in ic.loops(body).values()
+                  if any("v_sqrt_f32" in l for l in ls) and not any("global_store" in l or "flat_store" in l for l in ls)]
+        assert replay, f"no replay loop found in {name}"
+        for ls in replay:
+            assert not [l for l in ls if ic.VMEM_LOAD.search(l)], f"vector load inside a replay loop of {name}"
+        assert any("s_load_dwordx2" in l for ls in replay for l in ls), f"{name}: the constants do not come through the scalar cache"
+        seen += 1
+    assert seen == 2  # the unroll-1 and the unroll-4 instantiation
