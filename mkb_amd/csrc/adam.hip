@@ -585,7 +585,11 @@ namespace mkb {
 // arithmetic, same results bit for bit (every pending step of every row is replayed exactly once, whenever that happens);
 // cost: the window's rows x (p, m, v) in + out.  YAGO3-10: 99 -> 64 us per launch, step 0.268 -> 0.211 ms; WN18RR / FB15k-237
 // (mean gap 18 / 6 steps, every entity is a positive often enough): no gain, so no sweep.
-constexpr int kSweepPeriod = 64, kSweepMinGap = 32;
+// Round 5, with the replay's per-step round trips gone and in runs long enough for the gaps to reach their steady state (1,500
+// steps): WN18RR's launch 36.5 us without a sweep, 31.3-31.9 with a period of 24-48 (step 0.1193 -> 0.1144 ms), 32.5 at 128;
+// YAGO3-10 91.8 without, 53.1 / 54.5 / 65.1 / 79.0 at 32 / 64 / 128 / 256; FB15k-237 37.7 without, 37.7-39.1 with.  Hence: a
+// period of 32 from a mean gap of 12 steps on.
+constexpr int kSweepPeriod = 32, kSweepMinGap = 12;
 
 static void set_row_blocks(AdamRowArgs &A, int64_t rows, int64_t n_table = 0) {
     int64_t sweep = 0;
