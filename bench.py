@@ -715,6 +715,47 @@ def main():
     # RCCL feature missing on the box), fall back rather than lose the line -- the failure is reported in the line.
     order = [args.parallelism] + ([p for p in ("dims", "rows") if p != args.parallelism] if world > 1 else [])
     res, failures = None, {}
+    # N > 1 on real GPUs: the row-sharded step's collectives are issued by libmkb_hip.so through its own RCCL communicators, a
+    # form no round could run on more than one GPU.  So a SHORT measurement with the collectives in torch.distributed (the
+    # round-4 form: plain all_reduce / all_to_all_single) comes first, and a watchdog prints THAT line if the library-issued
+    # form has not finished in time -- a hang must not cost the driver its line (and the box its GPUs).
+    safety, dog_main = None, None
+    if (world > 1 and (not one_dev or os.environ.get("MKB_BENCH_FORCE_SAFETY", "0") == "1")  # (forced: the one-device functional check)
+            and order[0] == "table-rows" and os.environ.get("MKB_ROWS_PY_COLLECTIVES", "0") != "1"
+            and os.environ.get("MKB_BENCH_NO_SAFETY", "0") != "1"):
+        import threading
+
+        os.environ["MKB_ROWS_PY_COLLECTIVES"] = "1"
+        try:
+            r0 = measure(args, device, rank, world, args.config, "table-rows", min(args.steps, 40), min(args.warmup, 5), profile=False,
+                         force=args.force_parallelism)
+            safety = {"value": r0["value"], "ms_per_step": r0["ms_per_step"], "loss": r0["loss"], "steps": min(args.steps, 40),
+                      "warmup": min(args.warmup, 5), "rows_per_rank": r0["ctx"]["rows_per_rank"],
+                      "parallelism": parallelism_label(r0["ctx"], world)}
+            del r0
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: torch.distributed form of table-rows failed: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr)
+        finally:
+            os.environ["MKB_ROWS_PY_COLLECTIVES"] = "0"
+
+        def bail_main():
+            if rank == 0:
+                line = {"metric": "scored triples/sec (pos+K neg), FB15k-237 RotatE d=1000" if args.config == "headline"
+                        else f"scored triples/sec (pos+K neg), {args.config}", "value": safety["value"] if safety else None,
+                        "unit": "triples/s", "n_gpus": world, "steps": safety["steps"] if safety else 0,
+                        "warmup": safety["warmup"] if safety else 0, "ms_per_step": safety["ms_per_step"] if safety else None,
+                        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "see the N=1 line",
+                        "config": {"workload": args.config, "global_batch": world * safety["rows_per_rank"] if safety else None,
+                                   "negatives": K, "parallelism": safety["parallelism"] if safety else "table-rows"},
+                        "loss": safety["loss"] if safety else None, "roofline": None, "cpu_baseline": None,
+                        "error": "the library-issued RCCL collectives did not finish in time; this line is the short measurement "
+                                 "with the collectives issued by torch.distributed (MKB_ROWS_PY_COLLECTIVES=1)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0 if safety else 3)
+
+        dog_main = threading.Timer(float(os.environ.get("MKB_BENCH_MAIN_TIMEOUT", "240")), bail_main)
+        dog_main.daemon = True
+        dog_main.start()
     for par in order:
         try:
             res = measure(args, device, rank, world, args.config, par, args.steps, args.warmup, force=args.force_parallelism)
@@ -725,6 +766,8 @@ def main():
             failures[par] = f"{type(e).__name__}: {str(e)[:300]}"
             print(f"[bench] rank {rank}: parallelism {par} failed: {failures[par]}", file=sys.stderr)
             torch.cuda.synchronize()
+    if dog_main is not None:
+        dog_main.cancel()
     if res is None:
         raise SystemExit(f"every partitioning failed: {failures}")
     ctx = res["ctx"]
@@ -754,6 +797,8 @@ def main():
             out["roofline"]["step"] = step_roofline(res, world)
         if failures:
             out["partitioning_failures"] = failures
+        if safety is not None:
+            out["torch_distributed_form"] = {k: safety[k] for k in ("value", "ms_per_step", "steps", "warmup", "loss")}
         if ctx["trows"]:
             from mkb_amd.table_rows import _collectives_run, _Route
 

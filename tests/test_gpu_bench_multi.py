@@ -79,3 +79,30 @@ def test_bench_table_rows_code_path_on_one_rank():
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["parallelism"].startswith("table-rows1") and d["value"] > 0
+
+
+@pytest.mark.parametrize("timeout", [None, "0.2"])
+def test_bench_safety_line_of_the_row_sharded_step(timeout):
+    """N > 1: a short measurement with the collectives in torch.distributed runs in front of the library-issued form and rides
+    the line (``torch_distributed_form``); a watchdog prints it as the line when the main measurement does not finish in time
+    (forced here with a timeout no measurement can meet).  One device, gloo: MKB_BENCH_FORCE_SAFETY=1 switches the path on."""
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MKB_BENCH_ONE_DEVICE="1", MKB_BENCH_FORCE_SAFETY="1")
+    env.pop("MKB_BENCH_PARALLELISM", None)
+    if timeout:
+        env["MKB_BENCH_MAIN_TIMEOUT"] = timeout
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "60" if timeout else "4", "--warmup", "2",
+           "--config", "wn18rr-rotate", "--no-extras"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"].startswith("table-rows2")
+    if timeout:
+        assert "did not finish in time" in d["error"] and d["steps"] == 40
+    else:
+        assert "error" not in d and d["torch_distributed_form"]["value"] > 0 and d["steps"] == 4
