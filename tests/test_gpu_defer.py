@@ -328,15 +328,20 @@ def test_autograd_backward_before_a_fused_step_in_one_optimizer_step_is_not_over
 
 
 @pytest.mark.parametrize("defer", [False, True])
-@pytest.mark.parametrize("name", ["RotatE", "TransE"])
-def test_readme_loop_keeps_the_row_lazy_route(name, defer):
+@pytest.mark.parametrize("name", ["RotatE", "TransE", "RotatE-plain"])
+def test_readme_loop_keeps_the_row_lazy_route(name, defer, monkeypatch):
     """The reference's own loop (README.md:448-474: ``model(sample)``, ``model(sample, negatives, mode)``, ``loss.backward()``,
     ``optimizer.step()``) with ``mkb_amd.optim.Adam(lazy_rows=True)``: the backward functions add their rows straight into
     ``.grad`` of the row-lazily stepped table and record them (``_gradshare.direct``), the forward passes bring the rows they
     read up to date -- no dense gradient goes through autograd, and the optimizer must STILL be on its row-lazy route at the
     end (it used to fall back to the dense kernel after the first step).  Same tables as ``torch.optim.Adam`` on a twin."""
     from mkb_amd import _links, losses, models, optim, sampling
+    import mkb_amd.models.base as model_base
 
+    plain = name.endswith("-plain")  # negatives without the sampler's pool description: the general kernels, candidate by candidate
+    name = name.split("-")[0]
+    if plain:
+        monkeypatch.setattr(model_base, "AUTO_POOL", False)
     N, R = 6000, 5
     ents, rels = {i: i for i in range(N)}, {i: i for i in range(R)}
     rs = np.random.RandomState(2)
@@ -358,6 +363,8 @@ def test_readme_loop_keeps_the_row_lazy_route(name, defer):
             opt.zero_grad()
             pos = m(s)
             neg = ns.generate(s, mode)
+            if plain:
+                neg = neg.clone()
             err = crit(pos, m(s, neg, mode), w)
             err.backward()
             if fast and it == 4:  # a second backward pass before one step (gradient accumulation)
