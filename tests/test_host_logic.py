@@ -188,3 +188,35 @@ def test_row_lazy_replay_loop_has_no_vector_memory_load(tmp_path):
         assert any("s_load_dwordx2" in l for ls in replay for l in ls), f"{name}: the constants do not come through the scalar cache"
         seen += 1
     assert seen == 2  # the unroll-1 and the unroll-4 instantiation
+
+
+def test_weak_id_table_is_keyed_by_identity_and_forgets_dead_parameters():
+    """mkb_amd._links.WeakIdTable (the side tables that tie a parameter to its row-lazy optimizer): identity keys -- two equal
+    tensors are two keys --, values replaced in place, entries gone with their parameter."""
+    import gc
+
+    from mkb_amd._links import WeakIdTable
+
+    t = WeakIdTable()
+    a, b = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    t[a] = 1
+    t[b] = 2
+    t[a] = 3
+    assert t.get(a) == 3 and t[b] == 2 and a in t and len(t) == 2
+    assert t.pop(a) == 3 and a not in t and t.get(a, 7) == 7 and t.pop(a, "gone") == "gone"
+    with pytest.raises(KeyError):
+        t[a]
+    del b
+    gc.collect()
+    assert len(t) == 0
+
+
+def test_pipeline_host_stager_is_a_plain_copy_off_the_gpu():
+    """compose.pipeline._HostStager stages host batches through page-locked buffers for a ROCm device; for any other device (the
+    reference's default device="cpu") it must be the plain ``.to(device)`` of the reference's loop."""
+    from mkb_amd.compose.pipeline import _HostStager
+
+    s = _HostStager("cpu")
+    x, w = torch.arange(6).reshape(2, 3), torch.ones(2)
+    y, v = s(x, w)
+    assert torch.equal(x, y) and torch.equal(w, v) and y.device.type == "cpu"
