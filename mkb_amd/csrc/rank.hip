@@ -9,10 +9,14 @@
 // Kernel 1  all_fwd : scores of B queries against every entity row.  Same lane-owns-dims tiling as the pooled
 //           forward (8 rows per 1024-lane workgroup, swap/DPP wave reduction, LDS cross-wave combine per 16
 //           candidates) but the candidates are simply consecutive table rows, split into slices over grid.y.
+//           RotatE / TransE: the pooled forward's outer-product register tile instead (run_rank).
 // Kernel 2  rank    : one wave per query: count scores above the target's, then walk the query's true set
 //           (a contiguous range of the sorted key array) and take back the ones that were counted.
 #include "common.h"
 #include "model_math.h"
+#include "score_pool_tile.h"  // the pooled forward's outer-product register tile, for the all-entity block of RotatE / TransE
+
+#include <stdlib.h>
 
 namespace mkb {
 
@@ -146,19 +150,22 @@ __device__ __forceinline__ bool ranks_before(float a, int64_t ia, float b, int64
 }
 
 // one wave per query
+// (c0, c1): S holds finished scores (0, 1) or the raw pair sums of the register-tile route, finished here as c0 + c1 * sum -- the
+// same fp32 operation the all-entity kernel applies, so that ties fall as they do there
 __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, const int64_t *__restrict__ sample, int B,
                                                    int64_t N, int64_t R, int head_mode,
                                                    const int64_t *__restrict__ keys, int64_t nk,
-                                                   int64_t *__restrict__ rank) {
+                                                   int64_t *__restrict__ rank, float c0, float c1) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
     const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
     const int64_t target = head_mode ? h : t;
     const float *row = S + (int64_t)i * N;
-    const float st = row[target];
+    auto val = [&](int64_t e) { return c0 + c1 * row[e]; };
+    const float st = val(target);
     int64_t cnt = 0;
-    for (int64_t e = lane; e < N; e += 64) cnt += ranks_before(row[e], e, st, target) ? 1 : 0;
+    for (int64_t e = lane; e < N; e += 64) cnt += ranks_before(val(e), e, st, target) ? 1 : 0;
     // other true triples (base.py:213-216 / 229-232): take back those that were counted
     const int64_t base = ((head_mode ? t : h) * R + r) * N;  // keys of this (fixed entity, relation) pair are contiguous
     int64_t lo = 0, hi = nk;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, 
         const int64_t key = keys[k];
         if (key >= base + N) break;
         const int64_t e = key - base;
-        if (e != target && ranks_before(row[e], e, st, target)) cnt -= 1;
+        if (e != target && ranks_before(val(e), e, st, target)) cnt -= 1;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
@@ -202,13 +209,40 @@ __global__ __launch_bounds__(256) void query_build_kernel_r(RowArgsR A) {
     }
 }
 
+__global__ __launch_bounds__(256) void iota_kernel(int64_t *ids, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids[i] = i;
+}
+
 template <int MODEL, bool HEAD>
 static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, const int64_t *keys, int64_t nk, int64_t *rank,
-                    float *Q, float *S, hipStream_t st) {
+                    float *Q, float *S, int64_t *ids, hipStream_t st) {
     RowArgsR ra{tb->ent, tb->rel, sample, Q, tb->entity_dim, tb->relation_dim, tb->hidden_dim, tb->phase_div};
     hipLaunchKernelGGL((query_build_kernel_r<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
-    AllArgs A{tb->ent, Q, S, tb->modulus, (int)B, tb->hidden_dim, tb->n_entity, tb->entity_dim, tb->phase_div,
-              ModelTraits<MODEL>::uses_gamma ? tb->gamma : 0.f, ModelTraits<MODEL>::uses_gamma ? -1.f : 1.f};
+    const float c0 = ModelTraits<MODEL>::uses_gamma ? tb->gamma : 0.f, c1 = ModelTraits<MODEL>::uses_gamma ? -1.f : 1.f;
+    // RotatE / TransE: the all-entity block on the pooled forward's register tile (score_pool_tile.h: 64 queries x 64 entities per
+    // workgroup, 4 x 4 pairs per lane, operands staged through LDS -- no per-candidate wave reduction at all), the "pool" being
+    // every entity in order and nothing masked; S then holds raw pair sums, finished by the rank kernel.  MKB_RANK_TILE=0: A/B.
+    if constexpr (ModelTraits<MODEL>::cplx_pair || MODEL == MKB_TRANSE) {
+        static const bool tile_off = getenv("MKB_RANK_TILE") && getenv("MKB_RANK_TILE")[0] == '0';
+        const bool shape_ok = ModelTraits<MODEL>::cplx_pair ? (tb->hidden_dim % 4 == 0 && tb->hidden_dim >= 32)
+                                                            : (tb->entity_dim % 4 == 0 && tb->entity_dim >= 64);
+        if (!tile_off && shape_ok && (((uintptr_t)tb->ent | (uintptr_t)Q | (uintptr_t)S) & 15) == 0 && ids && tb->n_entity < (1 << 30)) {
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((tb->n_entity + 255) / 256)), dim3(256), 0, st, ids, tb->n_entity);
+            PoolArgs P{};
+            P.ent = tb->ent; P.Q = Q; P.pool = ids; P.B = (int)B; P.P = (int)tb->n_entity; P.d = tb->hidden_dim; P.De = tb->entity_dim;
+            P.kd = tb->phase_div; P.c0 = c0; P.c1 = c1;
+            TileArgs T{};
+            T.part = S; T.Kd = (int)tb->n_entity; T.ks = 1;
+            T.row_tiles = (int)((B + kTileRows - 1) / kTileRows); T.pos_tiles = (int)((tb->n_entity + kTilePos - 1) / kTilePos);
+            hipLaunchKernelGGL((pool_fwd_tile_kernel<MODEL, HEAD, 2>), dim3((unsigned)(T.row_tiles * T.pos_tiles)), dim3(256), 0, st, P, T);
+            hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
+                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, c0, c1);
+            MKB_LAUNCH_CHECK();
+            return MKB_OK;
+        }
+    }
+    AllArgs A{tb->ent, Q, S, tb->modulus, (int)B, tb->hidden_dim, tb->n_entity, tb->entity_dim, tb->phase_div, c0, c1};
     const int tiles = (int)((B + TIr - 1) / TIr);
     int slices = (512 + tiles - 1) / tiles;  // aim for >= 2 workgroups per CU
     if (slices < 1) slices = 1;
@@ -222,7 +256,7 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
     else if (NU <= 2 * kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 2>), grid, dim3(kWGr), 0, st, A);
     else hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 4>), grid, dim3(kWGr), 0, st, A);
     hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank);
+                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -233,7 +267,8 @@ using namespace mkb;
 
 extern "C" int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B) {
     if (!tb || B <= 0) return 0;
-    return (int64_t)(((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255) + (int64_t)B * tb->n_entity * 4;
+    return (int64_t)(((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255) + (int64_t)(((size_t)B * tb->n_entity * 4 + 255) & ~(size_t)255) +
+           (int64_t)tb->n_entity * 8;
 }
 
 extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
@@ -247,14 +282,15 @@ extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B
     MKB_REQUIRE(NU <= 4 * kWGr, "rows of more than 4096 units are not supported");
     float *Q = (float *)ws;
     float *S = (float *)((unsigned char *)ws + (((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255));
+    int64_t *ids = (int64_t *)((unsigned char *)S + (((size_t)B * tb->n_entity * 4 + 255) & ~(size_t)255));  // [N] 0, 1, ... (tile route)
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode == MKB_MODE_HEAD;
     switch (tb->model) {
-        case MKB_TRANSE: return head ? run_rank<MKB_TRANSE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_TRANSE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
-        case MKB_ROTATE: return head ? run_rank<MKB_ROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_ROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
-        case MKB_COMPLEX: return head ? run_rank<MKB_COMPLEX, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_COMPLEX, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
-        case MKB_DISTMULT: return head ? run_rank<MKB_DISTMULT, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_DISTMULT, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
-        case MKB_PROTATE: return head ? run_rank<MKB_PROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, st) : run_rank<MKB_PROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, st);
+        case MKB_TRANSE: return head ? run_rank<MKB_TRANSE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_TRANSE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
+        case MKB_ROTATE: return head ? run_rank<MKB_ROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_ROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
+        case MKB_COMPLEX: return head ? run_rank<MKB_COMPLEX, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_COMPLEX, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
+        case MKB_DISTMULT: return head ? run_rank<MKB_DISTMULT, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_DISTMULT, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
+        case MKB_PROTATE: return head ? run_rank<MKB_PROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_PROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
     }
     return set_error(MKB_ERR_INVALID, "unknown model");
 }

@@ -487,14 +487,17 @@ def test_sharded_batch_with_global_weight_sum_equals_full_batch():
     np.testing.assert_allclose(m.relation_embedding.grad.cpu().numpy(), g_full[1].cpu().numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("hidden", [37, 64])
 @pytest.mark.parametrize("name", ["TransE", "RotatE", "ComplEx", "DistMult", "pRotatE"])
-def test_device_ranking_equals_reference_route(name):
-    """mkb_rank (tiled all-entity forward + on-device filtered count) == TestDataset + general forward + argsort."""
+def test_device_ranking_equals_reference_route(name, hidden):
+    """mkb_rank (tiled all-entity forward + on-device filtered count) == TestDataset + general forward + argsort.
+    (hidden 64: RotatE and TransE take the pooled forward's register tile for the all-entity block, the others and hidden 37 the
+    lane-owns-dims kernel.)"""
     from mkb_amd import datasets, evaluation, models
 
     ds = datasets.Umls(batch_size=8, shuffle=False, seed=42, num_workers=0)
     torch.manual_seed(3)
-    m = getattr(models, name)(hidden_dim=37, entities=ds.entities, relations=ds.relations, gamma=6).cuda().eval()
+    m = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=6).cuda().eval()
     ev = evaluation.Evaluation(true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations, batch_size=64,
                                device="cuda", num_workers=0)
     test = ds.test[:150]
