@@ -600,6 +600,7 @@ __global__ __launch_bounds__(256) void gemm128_bf16x3_pair_kernel(GemmArgs G1, G
 }
 
 // out[i] = c0 + c1 * sum_z part[z][i]   (fixed order: deterministic)
+template <int UNUSED = 0>  // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t n,
                                                             int nz, float c0, float c1) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -639,6 +640,7 @@ __device__ __forceinline__ void splitk_scatter_block(const float *__restrict__ p
     }
 }
 
+template <int UNUSED = 0>  // (as above)
 __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__restrict__ part, float *__restrict__ out,
                                                              const int64_t *__restrict__ c_idx, int M, int N, int64_t ldc, int nz,
                                                              const int *__restrict__ depth, int n_depth) {
@@ -716,7 +718,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
                 if (int rc = narrow ? launch128(store_t{}, tn64_t{}, P2) : launch128(store_t{}, tn128_t{}, P2)) return rc;
                 const int *dp = G.depth_mode == 3 ? G.depth : nullptr;
                 if (tail) *tail = GemmTail{2, partials, final_c, G.c_idx, G.M, G.N, ks, G.ldc, 0, 0.f, 1.f, dp, G.n_depth};
-                else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M,
+                else hipLaunchKernelGGL(splitk_scatter_kernel<0>, dim3((unsigned)G.M), dim3(256), 0, st, partials, final_c, G.c_idx, G.M,
                                         G.N, G.ldc, ks, dp, G.n_depth);
                 MKB_LAUNCH_CHECK();
                 return MKB_OK;
@@ -728,7 +730,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
                 const int64_t n = (int64_t)G.M * G.ldc;
                 const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
                 if (tail) *tail = GemmTail{1, partials, final_c, nullptr, G.M, G.N, ks, G.ldc, n, c0, c1, nullptr, 0};
-                else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
+                else hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
             }
             MKB_LAUNCH_CHECK();
             return MKB_OK;
@@ -751,7 +753,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
     if (ks > 1 && EPI != GEMM_ATOMIC_ROWS && !to_slices) {
         const int64_t n = (int64_t)G.M * G.ldc;
         const float c0 = EPI == GEMM_STORE_AFFINE ? G.c0 : 0.f, c1 = EPI == GEMM_STORE_AFFINE ? G.c1 : 1.f;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
+        hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(512), dim3(256), 0, st, partials, final_c, n, ks, c0, c1);
     }
     MKB_LAUNCH_CHECK();
     return MKB_OK;
@@ -815,7 +817,7 @@ static int launch_gemm_bwd_pair(GemmArgs GQ, int slices_cap, int *slices_used, G
     if (rc) return rc;
     const int *dp = GX.depth_mode == 3 ? GX.depth : nullptr;
     if (x_tail) *x_tail = GemmTail{2, partials, GX.C, GX.c_idx, GX.M, GX.N, px.ks, GX.ldc, 0, 0.f, 1.f, dp, GX.n_depth};
-    else hipLaunchKernelGGL(splitk_scatter_kernel, dim3((unsigned)GX.M), dim3(256), 0, st, partials, GX.C, GX.c_idx, GX.M, GX.N, GX.ldc,
+    else hipLaunchKernelGGL(splitk_scatter_kernel<0>, dim3((unsigned)GX.M), dim3(256), 0, st, partials, GX.C, GX.c_idx, GX.M, GX.N, GX.ldc,
                             px.ks, dp, GX.n_depth);
     MKB_LAUNCH_CHECK();
     *done = true;

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "model_math.h"
 #include "score_pool_tile.h"  // the pooled forward's outer-product register tile, for the all-entity block of RotatE / TransE
+#include "gemm_mfma.h"        // ... and the matrix-core product for ComplEx / DistMult, whose score is a dot product
 
 #include <stdlib.h>
 
@@ -155,13 +156,13 @@ __device__ __forceinline__ bool ranks_before(float a, int64_t ia, float b, int64
 __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, const int64_t *__restrict__ sample, int B,
                                                    int64_t N, int64_t R, int head_mode,
                                                    const int64_t *__restrict__ keys, int64_t nk,
-                                                   int64_t *__restrict__ rank, float c0, float c1) {
+                                                   int64_t *__restrict__ rank, float c0, float c1, int64_t ld) {  // ld: floats between rows of S
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
     const int64_t h = sample[3 * (int64_t)i], r = sample[3 * (int64_t)i + 1], t = sample[3 * (int64_t)i + 2];
     const int64_t target = head_mode ? h : t;
-    const float *row = S + (int64_t)i * N;
+    const float *row = S + (int64_t)i * ld;
     auto val = [&](int64_t e) { return c0 + c1 * row[e]; };
     const float st = val(target);
     int64_t cnt = 0;
@@ -209,9 +210,10 @@ __global__ __launch_bounds__(256) void query_build_kernel_r(RowArgsR A) {
     }
 }
 
-__global__ __launch_bounds__(256) void iota_kernel(int64_t *ids, int64_t n) {
+// ids[i] = min(i, n_real - 1) for i < n (n >= n_real: the padded tail repeats the last row)
+__global__ __launch_bounds__(256) void iota_kernel(int64_t *ids, int64_t n, int64_t n_real) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) ids[i] = i;
+    if (i < n) ids[i] = i < n_real ? i : n_real - 1;
 }
 
 template <int MODEL, bool HEAD>
@@ -228,7 +230,7 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
         const bool shape_ok = ModelTraits<MODEL>::cplx_pair ? (tb->hidden_dim % 4 == 0 && tb->hidden_dim >= 32)
                                                             : (tb->entity_dim % 4 == 0 && tb->entity_dim >= 64);
         if (!tile_off && shape_ok && (((uintptr_t)tb->ent | (uintptr_t)Q | (uintptr_t)S) & 15) == 0 && ids && tb->n_entity < (1 << 30)) {
-            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((tb->n_entity + 255) / 256)), dim3(256), 0, st, ids, tb->n_entity);
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((tb->n_entity + 255) / 256)), dim3(256), 0, st, ids, tb->n_entity, tb->n_entity);
             PoolArgs P{};
             P.ent = tb->ent; P.Q = Q; P.pool = ids; P.B = (int)B; P.P = (int)tb->n_entity; P.d = tb->hidden_dim; P.De = tb->entity_dim;
             P.kd = tb->phase_div; P.c0 = c0; P.c1 = c1;
@@ -237,7 +239,28 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
             T.row_tiles = (int)((B + kTileRows - 1) / kTileRows); T.pos_tiles = (int)((tb->n_entity + kTilePos - 1) / kTilePos);
             hipLaunchKernelGGL((pool_fwd_tile_kernel<MODEL, HEAD, 2>), dim3((unsigned)(T.row_tiles * T.pos_tiles)), dim3(256), 0, st, P, T);
             hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, c0, c1);
+                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, c0, c1, tb->n_entity);
+            MKB_LAUNCH_CHECK();
+            return MKB_OK;
+        }
+    }
+    // ComplEx / DistMult: score = <q, x> over the entity row, so the all-entity block is ONE product Q [B, De] . E^T [De, N] on the
+    // matrix cores (gemm_mfma.h: 128-row tiles, fp32 operands split three ways on the bf16 pipe as in the pooled forward of these
+    // models).  N is padded to a multiple of 4 through the id list (the tail repeats the last row; the rank kernel never reads it),
+    // S rows are Npad floats apart.  Ragged last batches (B % 4 != 0) keep the lane-owns-dims kernel.  MKB_RANK_GEMM=0: A/B.
+    if constexpr (MODEL == MKB_COMPLEX || MODEL == MKB_DISTMULT) {
+        static const bool gemm_off = getenv("MKB_RANK_GEMM") && getenv("MKB_RANK_GEMM")[0] == '0';
+        const int64_t Npad = (tb->n_entity + 3) & ~(int64_t)3;
+        if (!gemm_off && ids && B % 4 == 0 && tb->entity_dim % 4 == 0 && tb->entity_dim >= 16 && B >= 32 &&
+            (((uintptr_t)tb->ent | (uintptr_t)Q | (uintptr_t)S) & 15) == 0 && Npad < (1 << 30)) {
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, st, ids, Npad, tb->n_entity);
+            GemmArgs G{};
+            G.A = Q; G.B = tb->ent; G.C = S; G.b_idx = ids; G.b_rows = tb->n_entity;
+            G.M = (int)B; G.N = (int)Npad; G.K = (int)tb->entity_dim; G.ksplit = 1;
+            G.lda = tb->entity_dim; G.ldb = tb->entity_dim; G.ldc = Npad; G.c0 = c0; G.c1 = c1;
+            if (int rc = launch_gemm<true, true, GEMM_STORE_AFFINE>(G, st, /*partials (unused: no K split at this size)=*/S)) return rc;
+            hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
+                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f, Npad);
             MKB_LAUNCH_CHECK();
             return MKB_OK;
         }
@@ -256,7 +279,7 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
     else if (NU <= 2 * kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 2>), grid, dim3(kWGr), 0, st, A);
     else hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 4>), grid, dim3(kWGr), 0, st, A);
     hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f);
+                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f, tb->n_entity);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -267,8 +290,8 @@ using namespace mkb;
 
 extern "C" int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B) {
     if (!tb || B <= 0) return 0;
-    return (int64_t)(((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255) + (int64_t)(((size_t)B * tb->n_entity * 4 + 255) & ~(size_t)255) +
-           (int64_t)tb->n_entity * 8;
+    return (int64_t)(((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255) + (int64_t)(((size_t)B * (tb->n_entity + 3) * 4 + 255) & ~(size_t)255) +
+           (int64_t)(tb->n_entity + 3) * 8;
 }
 
 extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
@@ -282,7 +305,7 @@ extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B
     MKB_REQUIRE(NU <= 4 * kWGr, "rows of more than 4096 units are not supported");
     float *Q = (float *)ws;
     float *S = (float *)((unsigned char *)ws + (((size_t)B * tb->entity_dim * 4 + 255) & ~(size_t)255));
-    int64_t *ids = (int64_t *)((unsigned char *)S + (((size_t)B * tb->n_entity * 4 + 255) & ~(size_t)255));  // [N] 0, 1, ... (tile route)
+    int64_t *ids = (int64_t *)((unsigned char *)S + (((size_t)B * (tb->n_entity + 3) * 4 + 255) & ~(size_t)255));  // [N + 3] 0, 1, ... (tile / GEMM routes)
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode == MKB_MODE_HEAD;
     switch (tb->model) {
