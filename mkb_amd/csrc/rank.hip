@@ -9,7 +9,8 @@
 // Kernel 1  all_fwd : scores of B queries against every entity row.  Same lane-owns-dims tiling as the pooled
 //           forward (8 rows per 1024-lane workgroup, swap/DPP wave reduction, LDS cross-wave combine per 16
 //           candidates) but the candidates are simply consecutive table rows, split into slices over grid.y.
-//           RotatE / TransE: the pooled forward's outer-product register tile instead (run_rank).
+//           RotatE / TransE: the pooled forward's outer-product register tile instead; ComplEx / DistMult: one matrix-core
+//           product (run_rank).
 // Kernel 2  rank    : one wave per query: count scores above the target's, then walk the query's true set
 //           (a contiguous range of the sorted key array) and take back the ones that were counted.
 #include "common.h"
