@@ -167,7 +167,18 @@ __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, 
     auto val = [&](int64_t e) { return c0 + c1 * row[e]; };
     const float st = val(target);
     int64_t cnt = 0;
-    for (int64_t e = lane; e < N; e += 64) cnt += ranks_before(val(e), e, st, target) ? 1 : 0;
+    // eight strides' loads at a time (a loop with a run-time trip count waits for every load before it issues the next: 227 round
+    // trips per query at FB15k-237's size)
+    for (int64_t e0 = lane; e0 < N; e0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = row[min(e0 + 64 * k, N - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t e = e0 + 64 * k;
+            cnt += (e < N && ranks_before(c0 + c1 * v[k], e, st, target)) ? 1 : 0;
+        }
+    }
     // other true triples (base.py:213-216 / 229-232): take back those that were counted
     const int64_t base = ((head_mode ? t : h) * R + r) * N;  // keys of this (fixed entity, relation) pair are contiguous
     int64_t lo = 0, hi = nk;
