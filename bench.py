@@ -27,6 +27,7 @@ Prints ONE JSON line (rank 0).  Extra objects: "roofline" for the dominant kerne
 timed region) and "cpu_baseline" (the oracle restatement of the reference's PyTorch-CPU path on a bounded sample).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -404,7 +405,7 @@ def measure_traffic(prof_kind, config):
                    + "; ".join(notes)), (names[0].split("(")[0].replace("void ", "") if names else None), step_table
 
 
-def measure(args, device, rank, world, config, parallelism, steps, warmup, profile=True, force=False):
+def measure(args, device, rank, world, config, parallelism, steps, warmup, profile=True, force=False, windows=1):
     """Build `config` under `parallelism`, warm up, time exactly `steps` steps between barriers (max over ranks).
     -> dict with the context, the timing and the HIP-event timing of the dominant kernel class."""
     import torch.distributed as dist
@@ -451,18 +452,58 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         # steps are both sampled); each bracket costs ~12 us of stream time, so bracketing every launch would tax every step
         _hip.profile_enable(prof_kind, 5)
 
+    # Everything the timed windows launch has run once before the first of them: the flush below is the process's first
+    # launch of the flush form of the advance kernel (bit-exact at any time), and a full garbage collection now + gc.freeze()
+    # takes the long-lived host objects (filter dictionaries, triples, modules) out of the collector's later passes -- a
+    # generation-2 pass over them lasts tens of milliseconds, ten times a 20-step window (see DESIGN.md section 0, r05's stall).
+    ctx["opt"].flush()
     barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = run_step(ctx, first + i)
-    ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
-    t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    gc_log = []
+    if not os.environ.get("MKB_BENCH_NO_GC_FREEZE"):
+        gc.collect()
+        gc.freeze()
+    gc_t = [0.0]
+
+    def gc_cb(phase, info):  # every collection that happens from here on is reported in the line, with its duration
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_log.append({"generation": info["generation"], "ms": round((time.perf_counter() - gc_t[0]) * 1e3, 3), "at": time.perf_counter()})
+
+    gc.callbacks.append(gc_cb)
+    # R windows of exactly `steps` steps each, every one between barriers; ms_per_step / value = the MEDIAN window, all of them
+    # are reported (windows_ms).  Per window: the host's enqueue time, the device's own time between two events on the step's
+    # stream, and the largest gap between two consecutive step submissions -- enough to tell a host stall from a device stall.
+    wins = []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for w in range(windows):
+        barrier()
+        ev0.record()
+        t0 = time.perf_counter()
+        prev, gap, gap_at = t0, 0.0, -1
+        for i in range(steps):
+            loss = run_step(ctx, first + w * steps + i)
+            now = time.perf_counter()
+            if now - prev > gap:
+                gap, gap_at = now - prev, i
+            prev = now
+        ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
+        t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        t1 = t0 + dt
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        wins.append({"ms": dt * 1e3, "host_enqueue_ms": t_host * 1e3, "device_ms": ev0.elapsed_time(ev1),
+                     "largest_submit_gap_ms": gap * 1e3, "largest_submit_gap_at_step": gap_at,
+                     "gc_ms": sum(e["ms"] for e in gc_log if t0 <= e["at"] <= t1)})
+    gc.callbacks.remove(gc_cb)
+    order_ = sorted(range(windows), key=lambda j: wins[j]["ms"])
+    med = wins[order_[(windows - 1) // 2]]  # (lower median for an even count: an actual window, not a mean of two)
+    dt, t_host = med["ms"] / 1e3, med["host_enqueue_ms"] / 1e3
     if args.breakdown and rank == 0:
         print(f"host enqueue {t_host / steps * 1e3:.4f} ms/step of {dt / steps * 1e3:.4f} ms/step", file=sys.stderr)
     sampler_note = None
@@ -487,7 +528,8 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         launches, kms = _hip.profile_read(prof_kind)
         _hip.profile_enable(prof_kind, False)
     return dict(ctx=ctx, dt=dt, steps=steps, warmup=warmup, loss=float(loss.item()), launches=launches, kms=kms, prof_kind=prof_kind,
-                sampler_note=sampler_note, config=config, t_host=t_host,
+                sampler_note=sampler_note, config=config, t_host=t_host, windows=wins,
+                gc=[{k: e[k] for k in ("generation", "ms")} for e in gc_log],
                 value=world * ctx["rows_per_rank"] * (K + 1) * steps / dt, ms_per_step=dt / steps * 1e3)
 
 
@@ -644,6 +686,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=int(os.environ.get("MKB_BENCH_WINDOWS", "7")),
+                    help="timed windows of --steps steps each, back to back, every one between barriers; ms_per_step / value are "
+                         "the MEDIAN window and all of them are printed (windows_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the cpu_baseline sample (reference-faithful form)")
     ap.add_argument("--no-variants", action="store_true", help="skip the with/without optimizer & sampler step variants")
@@ -758,7 +803,8 @@ def main():
         dog_main.start()
     for par in order:
         try:
-            res = measure(args, device, rank, world, args.config, par, args.steps, args.warmup, force=args.force_parallelism)
+            res = measure(args, device, rank, world, args.config, par, args.steps, args.warmup, force=args.force_parallelism,
+                          windows=max(1, args.windows))
             break
         except Exception as e:  # noqa: BLE001
             if world == 1:
@@ -791,6 +837,14 @@ def main():
                        "global_batch": world * ctx["rows_per_rank"], "negatives": K,
                        "parallelism": parallelism_label(ctx, world)},
             "loss": res["loss"],
+            # the timed region: `windows` back-to-back windows of `steps` steps, each between barriers; ms_per_step and value
+            # are the MEDIAN window; nothing is dropped -- every window is listed
+            "windows": len(res["windows"]), "windows_ms": [round(w["ms"], 4) for w in res["windows"]],
+            "windows_ms_per_step": [round(w["ms"] / args.steps, 5) for w in res["windows"]],
+            "windows_spread": (max(w["ms"] for w in res["windows"]) - min(w["ms"] for w in res["windows"])) / res["dt"] / 1e3,
+            "t_host_ms_per_step": res["t_host"] / args.steps * 1e3,
+            "windows_detail": [{k: round(v, 4) if isinstance(v, float) else v for k, v in w.items()} for w in res["windows"]],
+            "gc_collections_during_windows": res["gc"],
             "roofline": roofline_of(res, world, want_traffic=default_run and not args.no_traffic and res["prof_kind"] != "none"),
         }
         if out["roofline"] is not None:
@@ -805,7 +859,7 @@ def main():
             comm = getattr(ctx["step"], "_comm", None)
             out["table_rows"] = {"collectives_issued": bool(_collectives_run(world)), "backend": dist.get_backend() if dist is not None and dist.is_initialized() else None,
                                  "issued_by": "libmkb_hip.so (own RCCL communicators: mkb_rows_comm_*)" if comm else "torch.distributed",
-                                 "steps_counted": args.warmup + 8 + args.steps}
+                                 "steps_counted": args.warmup + 8 + args.steps * len(res["windows"])}
             if comm:
                 st = comm.stats()
                 out["table_rows"].update(st, host_waits_that_blocked=st["waited_with_idle_stream"],
@@ -867,7 +921,7 @@ def main():
         return
     ctx = res["ctx"]
     if world == 1 and args.mrr_epochs > 0 and not ctx["trows"]:
-        out["mrr"] = train_and_rank(ctx, args.mrr_epochs, args.warmup + 8 + args.steps)
+        out["mrr"] = train_and_rank(ctx, args.mrr_epochs, args.warmup + 8 + args.steps * len(res["windows"]))
     if world == 1 and args.config == "headline" and not args.no_variants and not ctx["trows"]:
         out["step_variants"] = step_variants(ctx)
     if not args.no_cpu_baseline and world == 1:

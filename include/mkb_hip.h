@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MKB_ABI_VERSION 5
+#define MKB_ABI_VERSION 6
 
 typedef enum {
     MKB_OK = 0,
@@ -319,7 +319,8 @@ int mkb_adam_rows_advance_sharded_generate(float *param, float *grad, float *exp
  *   returns to the host except through the mailbox below.  bad: as mkb_rows_route; bit 2 = a peer's block was malformed.
  * mkb_rows_comm_take: the split sizes of that plan -- sent_host [world] rows this rank asks each owner for, wanted_host [world]
  *   rows each rank asks this owner for -- read from a host-coherent mailbox the plan's last kernel wrote (no HIP call; spins
- *   only when the plan has not executed yet), and `stream` is made to wait for the plan.
+ *   only when the plan has not executed yet -- for at most MKB_ROWS_TAKE_TIMEOUT_S seconds (default 120), then MKB_ERR_HIP), and
+ *   `stream` is made to wait for the plan.
  * mkb_rows_comm_exchange: on `stream`: the all-reduce (sum, in place) of reduce [reduce_n] floats (0 = none), then ONE RCCL
  *   group with the all-to-all of rows of D floats (MKB_ROWS_ONE_GROUP=1, and always at world 1: both in one group): send_rows_host[p] rows to rank p from `send` (consecutive), recv_rows_host[p] rows from
  *   rank p into `recv` (null count vectors = no all-to-all).  Forward: owners send `wanted`, users receive `sent`; the
@@ -344,6 +345,15 @@ int mkb_rows_blocks_unpack(const int64_t *blocks, const int64_t *counts, int64_t
                            int64_t seq, int32_t *bad, int world, int64_t cap, void *stream);
 int mkb_rows_comm_available(void);
 int mkb_rows_comm_unique_id(uint8_t *id_host);
+/* In-process transport (ABI 6): RCCL refuses two ranks on one device, so plan / take / exchange cannot be driven for world > 1 on a
+ * one-GPU box through it.  A communicator made by mkb_rows_comm_create_loopback moves its blocks and rows through a hub in THIS
+ * process instead (device-to-device copies ordered by events, contributions of the all-reduce added in rank order): every rank is a
+ * host thread with its own streams, all on the current device, and all the entry points above behave as they do over RCCL --
+ * except that a peer that never makes the matching call, or disagrees about a split size, produces an ERROR after
+ * MKB_ROWS_LOOP_TIMEOUT_S (default 20) seconds where RCCL would hang.  tests/test_gpu_rows_loopback.py; not used by the product. */
+int mkb_rows_loop_hub_create(int world, void **hub);
+void mkb_rows_loop_hub_destroy(void *hub);  /* after the communicators made over it */
+int mkb_rows_comm_create_loopback(void *hub, int rank, int64_t max_requests, mkb_rows_comm_t **out);
 int mkb_rows_comm_create(const uint8_t *id_host, int rank, int world, int64_t max_requests, mkb_rows_comm_t **out);
 void mkb_rows_comm_destroy(mkb_rows_comm_t *comm);
 int mkb_rows_comm_plan(mkb_rows_comm_t *comm, int slot, const int64_t *sample, int64_t b, int64_t row0, int64_t *send_ids,
@@ -366,6 +376,12 @@ int mkb_rows_comm_stats(mkb_rows_comm_t *comm, int64_t *plans, int64_t *takes_th
 int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B);
 int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
              int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream);
+/* mkb_rank, and the score block the ranks were counted on handed out as well: scores [B, n_entity] fp32 =
+ * model(sample, negative_sample = every entity id in order, mode) of evaluation.py:237 BEFORE the filter bias is added
+ * (the same launches as mkb_rank plus one copy; the parity tests compare this block with the oracle's at full size, and
+ * utils-style "score against all entities" callers get it without a [B, N, D] gather).  ABI 6. */
+int mkb_rank_scores(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+                    int64_t n_true, int64_t *rank, float *scores, void *ws, int64_t ws_bytes, void *stream);
 
 /* ---- per-kernel timing (measurement aid, no reference counterpart) -------------------------------------
  * When enabled, the launches of the named kernel class are bracketed by hipEvents recorded on the SAME stream

@@ -14,7 +14,7 @@ import os
 
 # MKB_HIP_LIB selects an experimental build of the same ABI (tools/kbench.py); default = the in-tree product library
 _LIB_PATH = pathlib.Path(os.environ.get("MKB_HIP_LIB") or (pathlib.Path(__file__).resolve().parent / "libmkb_hip.so"))
-ABI_VERSION = 5  # == MKB_ABI_VERSION of include/mkb_hip.h (bumped whenever a symbol or a signature changes)
+ABI_VERSION = 6  # == MKB_ABI_VERSION of include/mkb_hip.h (bumped whenever a symbol or a signature changes)
 
 MODEL_IDS = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3, "pRotatE": 4}
 MODE_DEFAULT, MODE_HEAD, MODE_TAIL = 0, 1, 2
@@ -114,6 +114,9 @@ _SIGNATURES = {
     "mkb_rows_comm_unique_id": (c_int, [c_void_p]),
     "mkb_rows_comm_create": (c_int, [c_void_p, c_int, c_int, c_int64, POINTER(c_void_p)]),
     "mkb_rows_comm_destroy": (None, [c_void_p]),
+    "mkb_rows_loop_hub_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "mkb_rows_loop_hub_destroy": (None, [c_void_p]),
+    "mkb_rows_comm_create_loopback": (c_int, [c_void_p, c_int, c_int64, POINTER(c_void_p)]),
     "mkb_rows_comm_plan": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_void_p, c_void_p, c_void_p]),
     "mkb_rows_comm_take": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -131,6 +134,8 @@ _SIGNATURES = {
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),
     "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                          c_void_p]),
+    "mkb_rank_scores": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -472,7 +472,10 @@ __global__ __launch_bounds__(kCatchThreads) void adam_rows_catchup_kernel(AdamRo
                                                           : A.seg_sample[3 * (r - A.seg_P - A.seg_B) + 2]);
         else row = r;
     }
-    if (row < 0) { valid = false; row = 0; }  // a negative id = "not a row of this table" (an entry another rank owns): skipped
+    // a negative id = "not a row of this table" (an entry another rank owns): skipped.  So is an id past the table (n_table is set
+    // whenever the rows come from an id list): the caller's id check raises the reference's IndexError for it afterwards
+    // (mkb_check_ids sets its flag asynchronously) -- the replay must not have written p / m / v / last out of bounds by then
+    if (row < 0 || (A.n_table > 0 && row >= A.n_table)) { valid = false; row = 0; }
     if (A.vec4) replay_row_block<4, UNROLL>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
     else replay_row_block<2, UNROLL>(A, row, valid, lane, lanes, &s_old2[sub], ahead);
 }
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(256) void adam_rows_step_kernel(AdamRowArgs A) {
     }
     if (bid == 0 && threadIdx.x == 0) A.consts[A.step] = make_float2(A.neg_step, A.sqrt_bc2);
     const int64_t row = A.ids[bid];
-    if (row < 0) return;  // (workgroup-uniform) an entry another rank owns in a row-sharded table's id list
+    if (row < 0 || (A.n_table > 0 && row >= A.n_table)) return;  // (workgroup-uniform) an entry another rank owns in a row-sharded table's id list, or an id past the table
     if (threadIdx.x == 0) s_old = atomicExch(&A.last[row], A.step);
     float *p = A.p + row * A.D, *g = A.g + row * A.D, *m = A.m + row * A.D, *v = A.v + row * A.D;
     if ((A.D & 3) == 0) {  // 16-byte aligned rows: one float4 per lane and array
@@ -796,11 +799,11 @@ extern "C" int mkb_adam_rows_advance_sharded_generate(float *param, float *grad,
 extern "C" int mkb_adam_rows_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int32_t *last, float *consts,
                                   int64_t n_rows, int64_t D, const int64_t *ids, int64_t n_ids, int64_t step, float lr,
                                   float beta1, float beta2, float eps, const mkb_adam_dense_t *rider, void *stream) {
-    (void)n_rows;
     mkb::AdamRowArgs A{};
     if (int rc = mkb::fill_args(A, param, grad, exp_avg, exp_avg_sq, last, consts, ids, D, step, lr, beta1, beta2, eps)) return rc;
     MKB_REQUIRE(grad && ids && step >= 1 && n_ids > 0 && n_ids <= INT32_MAX, "bad arguments");
     A.n_ids = (int32_t)n_ids;
+    A.n_table = n_rows;  // (ids past the table are skipped, not stepped out of bounds)
     int64_t extra = 0;
     if (rider && rider->n > 0) {
         MKB_REQUIRE(rider->param && rider->grad && rider->exp_avg && rider->exp_avg_sq && rider->step >= 1, "bad dense rider");

@@ -656,8 +656,10 @@ __global__ __launch_bounds__(256) void splitk_scatter_kernel(const float *__rest
 template <bool A_MK, bool B_NK, int EPI>
 // slices_cap > 0 (STORE epilogue): the caller's consumer adds up to slices_cap partial products itself -- C is [slices][M][ldc];
 // a K split then writes its partials straight there (no partial buffer, no reduction launch) and *slices_used says how many.
+// max_ks: the largest K split the plan may choose (1 = never split: a caller whose `partials` is only the permission to take
+// the 128-row tiles and holds no room for [ks][M][ldc] partial products -- the ranking route).
 static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, GemmTail *tail = nullptr, int want_wg = 0,
-                       int slices_cap = 0, int *slices_used = nullptr) {
+                       int slices_cap = 0, int *slices_used = nullptr, int max_ks = 8) {
     if (tail) tail->kind = 0;
     const bool to_slices = slices_cap > 0 && EPI == GEMM_STORE && slices_used;
     if (slices_used) *slices_used = 1;
@@ -675,7 +677,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
             // each SIMD's matrix pipe idle during its staging; measured 37 -> 29 us, the split-K sum rides the loss rows anyway)
             static const int env_wg = getenv("MKB_GEMM_MIN_WG") ? atoi(getenv("MKB_GEMM_MIN_WG")) : 0;  // experiment knob
             const int min_wg = env_wg ? env_wg : (want_wg ? want_wg : 200);
-            while (tiles * ks < min_wg && ks < 8 && G.K / (ks * 2) >= 96 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
+            while (tiles * ks < min_wg && ks < max_ks && G.K / (ks * 2) >= 96 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
             G.ksplit = ks;
             if (to_slices) *slices_used = ks;
             float *final_c = G.C;
@@ -741,7 +743,7 @@ static int launch_gemm(GemmArgs G, hipStream_t st, float *partials = nullptr, Ge
     const int tiles = half ? ((G.M + 31) / 32) * ((G.N + 63) / 64) : tiles64;
     int ks = 1;
     if (EPI == GEMM_ATOMIC_ROWS || partials || to_slices) {
-        while (tiles * ks < 768 && ks < 8 && G.K / (ks * 2) >= 128 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
+        while (tiles * ks < 768 && ks < max_ks && G.K / (ks * 2) >= 128 && (!to_slices || ks * 2 <= slices_cap)) ks *= 2;
     }
     G.ksplit = ks;
     if (to_slices) *slices_used = ks;

@@ -19,6 +19,7 @@
 #include "gemm_mfma.h"        // ... and the matrix-core product for ComplEx / DistMult, whose score is a dot product
 
 #include <stdlib.h>
+#include <algorithm>
 
 namespace mkb {
 
@@ -194,6 +195,14 @@ __global__ __launch_bounds__(256) void rank_kernel(const float *__restrict__ S, 
     if (lane == 0) rank[i] = cnt + 1;
 }
 
+// scores_out[i, e] = c0 + c1 * S[i * ld + e]: the finished score block the ranks were counted on, for callers that want the
+// scores themselves (mkb_rank_scores)
+__global__ __launch_bounds__(256) void export_scores_kernel(const float *__restrict__ S, float *__restrict__ out, int64_t N, int64_t ld,
+                                                            float c0, float c1) {
+    const int64_t i = blockIdx.y;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (int64_t)gridDim.x * 256) out[i * N + e] = c0 + c1 * S[i * ld + e];
+}
+
 struct RowArgsR {
     const float *ent, *rel;
     const int64_t *sample;
@@ -230,7 +239,15 @@ __global__ __launch_bounds__(256) void iota_kernel(int64_t *ids, int64_t n, int6
 
 template <int MODEL, bool HEAD>
 static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, const int64_t *keys, int64_t nk, int64_t *rank,
-                    float *Q, float *S, int64_t *ids, hipStream_t st) {
+                    float *Q, float *S, int64_t *ids, hipStream_t st, float *scores_out) {
+    // the last launch(es) of every route: count the filtered ranks on S (and hand the finished scores out when asked)
+    auto finish = [&](float f0, float f1, int64_t ld) {
+        hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
+                           tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, f0, f1, ld);
+        if (scores_out)
+            hipLaunchKernelGGL(export_scores_kernel, dim3((unsigned)std::min<int64_t>((tb->n_entity + 255) / 256, 64), (unsigned)B), dim3(256), 0, st,
+                               S, scores_out, tb->n_entity, ld, f0, f1);
+    };
     RowArgsR ra{tb->ent, tb->rel, sample, Q, tb->entity_dim, tb->relation_dim, tb->hidden_dim, tb->phase_div};
     hipLaunchKernelGGL((query_build_kernel_r<MODEL, HEAD>), dim3((unsigned)B), dim3(256), 0, st, ra);
     const float c0 = ModelTraits<MODEL>::uses_gamma ? tb->gamma : 0.f, c1 = ModelTraits<MODEL>::uses_gamma ? -1.f : 1.f;
@@ -250,8 +267,7 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
             T.part = S; T.Kd = (int)tb->n_entity; T.ks = 1;
             T.row_tiles = (int)((B + kTileRows - 1) / kTileRows); T.pos_tiles = (int)((tb->n_entity + kTilePos - 1) / kTilePos);
             hipLaunchKernelGGL((pool_fwd_tile_kernel<MODEL, HEAD, 2>), dim3((unsigned)(T.row_tiles * T.pos_tiles)), dim3(256), 0, st, P, T);
-            hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, c0, c1, tb->n_entity);
+            finish(c0, c1, tb->n_entity);
             MKB_LAUNCH_CHECK();
             return MKB_OK;
         }
@@ -270,9 +286,10 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
             G.A = Q; G.B = tb->ent; G.C = S; G.b_idx = ids; G.b_rows = tb->n_entity;
             G.M = (int)B; G.N = (int)Npad; G.K = (int)tb->entity_dim; G.ksplit = 1;
             G.lda = tb->entity_dim; G.ldb = tb->entity_dim; G.ldc = Npad; G.c0 = c0; G.c1 = c1;
-            if (int rc = launch_gemm<true, true, GEMM_STORE_AFFINE>(G, st, /*partials (unused: no K split at this size)=*/S)) return rc;
-            hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                               tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f, Npad);
+            // max_ks = 1: the workspace holds ONE [B, Npad] score block -- a K split would write its partial products past it
+            // (over the id list this very product gathers through).  `partials` = S only admits the 128-row tiles.
+            if (int rc = launch_gemm<true, true, GEMM_STORE_AFFINE>(G, st, /*partials=*/S, nullptr, 0, 0, nullptr, /*max_ks=*/1)) return rc;
+            finish(0.f, 1.f, Npad);
             MKB_LAUNCH_CHECK();
             return MKB_OK;
         }
@@ -290,8 +307,7 @@ static int run_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, co
     else if (NU <= kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 1>), grid, dim3(kWGr), 0, st, A);
     else if (NU <= 2 * kWGr) hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 2>), grid, dim3(kWGr), 0, st, A);
     else hipLaunchKernelGGL((all_fwd_kernel<MODEL, HEAD, 4>), grid, dim3(kWGr), 0, st, A);
-    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, S, sample, (int)B, tb->n_entity,
-                       tb->n_relation, HEAD ? 1 : 0, keys, nk, rank, 0.f, 1.f, tb->n_entity);
+    finish(0.f, 1.f, tb->n_entity);
     MKB_LAUNCH_CHECK();
     return MKB_OK;
 }
@@ -306,8 +322,8 @@ extern "C" int64_t mkb_rank_workspace_bytes(const mkb_tables_t *tb, int64_t B) {
            (int64_t)(tb->n_entity + 3) * 8;
 }
 
-extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
-                        int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream) {
+static int rank_impl(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+                     int64_t n_true, int64_t *rank, float *scores, void *ws, int64_t ws_bytes, void *stream) {
     if (int rc = validate_tables(tb)) return rc;
     MKB_REQUIRE(sample && rank && ws && (true_keys || n_true == 0), "null pointer");
     MKB_REQUIRE(mode == MKB_MODE_HEAD || mode == MKB_MODE_TAIL, "mkb_rank needs head-batch or tail-batch");
@@ -321,11 +337,22 @@ extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B
     hipStream_t st = (hipStream_t)stream;
     const bool head = mode == MKB_MODE_HEAD;
     switch (tb->model) {
-        case MKB_TRANSE: return head ? run_rank<MKB_TRANSE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_TRANSE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
-        case MKB_ROTATE: return head ? run_rank<MKB_ROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_ROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
-        case MKB_COMPLEX: return head ? run_rank<MKB_COMPLEX, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_COMPLEX, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
-        case MKB_DISTMULT: return head ? run_rank<MKB_DISTMULT, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_DISTMULT, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
-        case MKB_PROTATE: return head ? run_rank<MKB_PROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st) : run_rank<MKB_PROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st);
+        case MKB_TRANSE: return head ? run_rank<MKB_TRANSE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores) : run_rank<MKB_TRANSE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores);
+        case MKB_ROTATE: return head ? run_rank<MKB_ROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores) : run_rank<MKB_ROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores);
+        case MKB_COMPLEX: return head ? run_rank<MKB_COMPLEX, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores) : run_rank<MKB_COMPLEX, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores);
+        case MKB_DISTMULT: return head ? run_rank<MKB_DISTMULT, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores) : run_rank<MKB_DISTMULT, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores);
+        case MKB_PROTATE: return head ? run_rank<MKB_PROTATE, true>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores) : run_rank<MKB_PROTATE, false>(tb, sample, B, true_keys, n_true, rank, Q, S, ids, st, scores);
     }
     return set_error(MKB_ERR_INVALID, "unknown model");
+}
+
+extern "C" int mkb_rank(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+                        int64_t n_true, int64_t *rank, void *ws, int64_t ws_bytes, void *stream) {
+    return rank_impl(tb, sample, B, mode, true_keys, n_true, rank, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int mkb_rank_scores(const mkb_tables_t *tb, const int64_t *sample, int64_t B, int mode, const int64_t *true_keys,
+                               int64_t n_true, int64_t *rank, float *scores, void *ws, int64_t ws_bytes, void *stream) {
+    MKB_REQUIRE(scores, "null pointer");
+    return rank_impl(tb, sample, B, mode, true_keys, n_true, rank, scores, ws, ws_bytes, stream);
 }

@@ -26,9 +26,17 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enums only: every function is resolved with dlsym
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <algorithm>
+#include <vector>
 
 namespace mkb {
 
@@ -150,6 +158,59 @@ __global__ __launch_bounds__(1024) void rows_unpack_kernel(UnpackArgs A) {
     if (tid == 0) __hip_atomic_store(&A.mail->seq, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+
+// ---- in-process transport ("loopback") --------------------------------------------------------------------------------------
+// RCCL refuses two ranks on one device, and the boxes this code is developed on have one.  So that plan / take / exchange can be
+// driven for world > 1 anyway -- every rank a host thread of ONE process, all on one device, each with its own streams -- a
+// communicator can be created over a LoopHub instead of RCCL (mkb_rows_comm_create_loopback).  The hub gives the five calls the
+// step uses (group start / end, send, receive, all-reduce) the semantics RCCL gives them, stream-ordered:
+//   send / receive  a send posts (pointer, bytes, an event recorded on the sender's stream) in the FIFO of its (channel, source,
+//                   destination); the matching receive makes ITS stream wait for that event and copies device-to-device; the
+//                   sender's stream then waits for the copy (so its buffer may be reused, as after ncclSend).  Sizes must match:
+//                   a rank that disagrees with its peer about a split size is an ERROR here, where RCCL would hang or corrupt;
+//   all-reduce      contributions are staged in hub memory, every rank adds them up in RANK order (the same bits everywhere);
+//   rendez-vous     on the host, with a time-out (MKB_ROWS_LOOP_TIMEOUT_S, default 20 s): a peer that never makes the matching
+//                   call produces an error instead of a hang.
+// Test equipment inside the product library (it has to sit under the C ABI it tests); nothing selects it implicitly.
+struct LoopPost {
+    const void *ptr;
+    size_t bytes;
+    hipEvent_t ready, consumed;
+    bool taken;
+};
+
+struct LoopHub {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<LoopPost *> fifo[2][kCommMaxWorld][kCommMaxWorld];  // [channel][source][destination]
+    // all-reduce staging per channel
+    float *stage[2] = {nullptr, nullptr};
+    size_t stage_floats[2] = {0, 0};      // capacity per rank
+    int red_phase[2] = {0, 0}, red_arrived[2] = {0, 0}, red_left[2] = {0, 0};
+    size_t red_n[2] = {0, 0};
+    std::vector<float *> retired;         // outgrown staging areas (freed with the hub)
+    hipEvent_t red_ready[2][kCommMaxWorld] = {}, red_done[2][kCommMaxWorld] = {};
+    std::vector<hipEvent_t> events;       // everything the posts used (destroyed with the hub)
+    double timeout_s = 20.0;
+    int refs = 0;
+};
+
+__global__ __launch_bounds__(256) void loop_sum_kernel(const float *__restrict__ stage, float *__restrict__ out, size_t n, size_t pitch, int world) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = stage[i];
+        for (int r = 1; r < world; ++r) s += stage[(size_t)r * pitch + i];
+        out[i] = s;
+    }
+}
+
+struct LoopOp {
+    int kind;  // 0 send, 1 receive, 2 all-reduce
+    void *ptr;
+    size_t bytes;
+    int peer;
+};
+
 }  // namespace mkb
 
 using namespace mkb;
@@ -165,7 +226,142 @@ struct mkb_rows_comm {
     hipEvent_t after = nullptr;
     int64_t seq_of[kCommSlots] = {};
     int64_t plans = 0, waited = 0, waited_idle = 0;
+    // transport: RCCL (hub == nullptr) or the in-process hub (tests: several ranks as host threads on one device)
+    LoopHub *hub = nullptr;
+    bool in_group = false;
+    int group_chan = 0;
+    hipStream_t group_stream = nullptr;
+    std::vector<LoopOp> pending;
 };
+
+// ---- the five transport calls of the step, over RCCL or the hub.  chan: 0 = the plan's communicator, 1 = the step's.
+static int loop_flush(mkb_rows_comm *c);
+
+static int t_group_start(mkb_rows_comm *c) {
+    if (!c->hub) { MKB_CHECK_NCCL(rccl().GroupStart()); return MKB_OK; }
+    c->in_group = true;
+    c->pending.clear();
+    return MKB_OK;
+}
+
+// (also on error paths: a group that was opened is always closed, or the thread's RCCL group state stays open for good)
+static int t_group_end(mkb_rows_comm *c) {
+    if (!c->hub) { MKB_CHECK_NCCL(rccl().GroupEnd()); return MKB_OK; }
+    c->in_group = false;
+    return loop_flush(c);
+}
+
+static int t_op(mkb_rows_comm *c, int kind, void *ptr, size_t count, ncclDataType_t type, int peer, int chan, hipStream_t st) {
+    if (!c->hub) {
+        ncclComm_t comm = chan == 0 ? c->plan_comm : c->step_comm;
+        ncclResult_t r = kind == 0   ? rccl().Send(ptr, count, type, peer, comm, st)
+                         : kind == 1 ? rccl().Recv(ptr, count, type, peer, comm, st)
+                                     : rccl().AllReduce(ptr, ptr, count, type, ncclSum, comm, st);
+        if (r != ncclSuccess) {
+            const int rc = set_error(MKB_ERR_HIP, "RCCL %s failed: %s", kind == 0 ? "send" : kind == 1 ? "receive" : "all-reduce", rccl().GetErrorString(r));
+            return rc;
+        }
+        return MKB_OK;
+    }
+    const size_t bytes = count * (type == ncclInt64 ? 8 : 4);
+    c->group_chan = chan;
+    c->group_stream = st;
+    c->pending.push_back(LoopOp{kind, ptr, bytes, peer});
+    if (!c->in_group) return loop_flush(c);
+    return MKB_OK;
+}
+
+static hipEvent_t loop_event(LoopHub *h) {  // (called with the hub's mutex held)
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    h->events.push_back(e);
+    return e;
+}
+
+static int loop_flush(mkb_rows_comm *c) {
+    LoopHub *h = c->hub;
+    const int chan = c->group_chan, me = c->rank;
+    hipStream_t st = c->group_stream;
+    std::vector<LoopOp> ops;
+    ops.swap(c->pending);
+    if (ops.empty()) return MKB_OK;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(h->timeout_s));
+    std::unique_lock<std::mutex> lk(h->mu);
+    // 1. post the sends (one `ready` event for the group: everything queued on the stream so far)
+    hipEvent_t ready = loop_event(h);
+    MKB_CHECK_HIP(hipEventRecord(ready, st));
+    std::vector<LoopPost *> mine;
+    for (const LoopOp &o : ops)
+        if (o.kind == 0) {
+            LoopPost *p = new LoopPost{o.ptr, o.bytes, ready, nullptr, false};
+            h->fifo[chan][me][o.peer].push_back(p);
+            mine.push_back(p);
+        }
+    h->cv.notify_all();
+    // 2. the all-reduce, if any: stage, meet, add up in rank order.  Two phases per channel: 0 = collecting the contributions,
+    //    1 = every rank adds them up; back to 0 when the last rank has queued its sum.
+    for (const LoopOp &o : ops) {
+        if (o.kind != 2) continue;
+        const size_t n = o.bytes / 4;
+        if (!h->cv.wait_until(lk, deadline, [&] { return h->red_phase[chan] == 0; }))
+            return set_error(MKB_ERR_HIP, "loopback all-reduce: the previous one was never finished by every rank (rank %d)", me);
+        if (h->red_arrived[chan] == 0) {  // the first to arrive sizes the staging area
+            if (n > h->stage_floats[chan]) {  // (the old area may still be read by kernels in flight: it is kept until the hub goes)
+                if (h->stage[chan]) h->retired.push_back(h->stage[chan]);
+                h->stage_floats[chan] = n * 2;
+                MKB_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&h->stage[chan]), h->stage_floats[chan] * h->world * 4));
+            }
+            h->red_n[chan] = n;
+        } else if (h->red_n[chan] != n) {
+            return set_error(MKB_ERR_INVALID, "loopback all-reduce: rank %d reduces %zu floats, a peer %zu", me, n, h->red_n[chan]);
+        }
+        if (!h->red_ready[chan][me]) { h->red_ready[chan][me] = loop_event(h); h->red_done[chan][me] = loop_event(h); }
+        // (every rank has left the previous all-reduce of this channel, so its `done` event is recorded: my staging row is
+        // overwritten only after all of them have read it)
+        for (int r = 0; r < h->world; ++r)
+            if (h->red_done[chan][r]) MKB_CHECK_HIP(hipStreamWaitEvent(st, h->red_done[chan][r], 0));
+        MKB_CHECK_HIP(hipMemcpyAsync(h->stage[chan] + (size_t)me * h->stage_floats[chan], o.ptr, n * 4, hipMemcpyDeviceToDevice, st));
+        MKB_CHECK_HIP(hipEventRecord(h->red_ready[chan][me], st));
+        if (++h->red_arrived[chan] == h->world) { h->red_phase[chan] = 1; h->red_left[chan] = 0; h->cv.notify_all(); }
+        if (!h->cv.wait_until(lk, deadline, [&] { return h->red_phase[chan] == 1; }))
+            return set_error(MKB_ERR_HIP, "loopback all-reduce: only %d of %d ranks arrived (rank %d waited %.0f s)", h->red_arrived[chan], h->world, me, h->timeout_s);
+        for (int r = 0; r < h->world; ++r) MKB_CHECK_HIP(hipStreamWaitEvent(st, h->red_ready[chan][r], 0));
+        hipLaunchKernelGGL(loop_sum_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, st, h->stage[chan],
+                           reinterpret_cast<float *>(o.ptr), n, h->stage_floats[chan], h->world);
+        MKB_CHECK_HIP(hipEventRecord(h->red_done[chan][me], st));
+        if (++h->red_left[chan] == h->world) { h->red_phase[chan] = 0; h->red_arrived[chan] = 0; h->cv.notify_all(); }
+    }
+    // 3. the receives: wait for the peer's post, then copy behind its `ready` event
+    for (const LoopOp &o : ops) {
+        if (o.kind != 1) continue;
+        auto &q = h->fifo[chan][o.peer][me];
+        LoopPost *p = nullptr;
+        auto next = [&] { for (LoopPost *x : q) if (!x->taken) { p = x; return true; } return false; };
+        if (!h->cv.wait_until(lk, deadline, next))
+            return set_error(MKB_ERR_HIP, "loopback receive: rank %d never sent what rank %d waits for (channel %d, %.0f s)", o.peer, me, chan, h->timeout_s);
+        if (p->bytes != o.bytes)
+            return set_error(MKB_ERR_INVALID, "loopback receive: rank %d expects %zu bytes from rank %d, which sends %zu (split sizes disagree)", me, o.bytes, o.peer, p->bytes);
+        MKB_CHECK_HIP(hipStreamWaitEvent(st, p->ready, 0));
+        if (o.bytes) MKB_CHECK_HIP(hipMemcpyAsync(o.ptr, p->ptr, o.bytes, hipMemcpyDeviceToDevice, st));
+        p->consumed = loop_event(h);
+        MKB_CHECK_HIP(hipEventRecord(p->consumed, st));
+        p->taken = true;
+        h->cv.notify_all();
+    }
+    // 4. my sends: once a peer has taken one, my stream waits for its copy (the buffer may then be reused), and the post goes
+    for (LoopPost *p : mine) {
+        if (!h->cv.wait_until(lk, deadline, [&] { return p->taken; }))
+            return set_error(MKB_ERR_HIP, "loopback send: a peer of rank %d never made the matching receive (channel %d, %.0f s)", me, chan, h->timeout_s);
+        MKB_CHECK_HIP(hipStreamWaitEvent(st, p->consumed, 0));
+        for (int d = 0; d < h->world; ++d) {
+            auto &q = h->fifo[chan][me][d];
+            for (auto it = q.begin(); it != q.end(); ++it)
+                if (*it == p) { q.erase(it); break; }
+        }
+        delete p;
+    }
+    return MKB_OK;
+}
 
 // The two kernels of a plan on their own, for a caller that moves the blocks with a transport of its own (and for the tests, which
 // play several ranks in one process on one GPU: RCCL itself refuses two ranks on one device).
@@ -215,6 +411,59 @@ extern "C" void mkb_rows_comm_destroy(mkb_rows_comm_t *c) {
     delete c;
 }
 
+// the parts of a communicator that do not depend on the transport: the id blocks of the plans in flight, their events, the mailbox
+static int comm_alloc(mkb_rows_comm *c) {
+    const size_t block_bytes = sizeof(int64_t) * (size_t)c->world * (size_t)(1 + c->cap);
+    for (int s = 0; s < kCommSlots; ++s) {
+        if (hipMalloc(&c->send_block[s], block_bytes) != hipSuccess || hipMalloc(&c->recv_block[s], block_bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ready[s], hipEventDisableTiming) != hipSuccess)
+            return set_error(MKB_ERR_HIP, "allocation failed in mkb_rows_comm_create");
+    }
+    if (hipEventCreateWithFlags(&c->after, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->mail_host), sizeof(Mailbox) * kCommSlots, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&c->mail_dev), c->mail_host, 0) != hipSuccess)
+        return set_error(MKB_ERR_HIP, "mailbox allocation failed in mkb_rows_comm_create");
+    memset(c->mail_host, 0, sizeof(Mailbox) * kCommSlots);
+    return MKB_OK;
+}
+
+extern "C" int mkb_rows_loop_hub_create(int world, void **hub_out) {
+    MKB_REQUIRE(hub_out && world >= 1 && world <= kCommMaxWorld, "bad world (at most %d ranks)", kCommMaxWorld);
+    LoopHub *h = new LoopHub;
+    h->world = world;
+    if (const char *e = getenv("MKB_ROWS_LOOP_TIMEOUT_S")) { const double v = atof(e); if (v > 0) h->timeout_s = v; }
+    *hub_out = h;
+    return MKB_OK;
+}
+
+extern "C" void mkb_rows_loop_hub_destroy(void *hub) {
+    LoopHub *h = (LoopHub *)hub;
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (hipEvent_t e : h->events) if (e) (void)hipEventDestroy(e);
+    for (int ch = 0; ch < 2; ++ch) {
+        if (h->stage[ch]) (void)hipFree(h->stage[ch]);
+        for (int a = 0; a < kCommMaxWorld; ++a)
+            for (int b = 0; b < kCommMaxWorld; ++b)
+                for (LoopPost *p : h->fifo[ch][a][b]) delete p;
+    }
+    for (float *f : h->retired) (void)hipFree(f);
+    delete h;
+}
+
+extern "C" int mkb_rows_comm_create_loopback(void *hub, int rank, int64_t max_requests, mkb_rows_comm_t **out) {
+    LoopHub *h = (LoopHub *)hub;
+    MKB_REQUIRE(h && out, "null pointer");
+    MKB_REQUIRE(rank >= 0 && rank < h->world, "bad rank %d for a hub of %d ranks", rank, h->world);
+    MKB_REQUIRE(max_requests > 0 && max_requests <= (1 << 24), "bad request capacity");
+    mkb_rows_comm *c = new mkb_rows_comm;
+    c->rank = rank; c->world = h->world; c->cap = max_requests; c->hub = h;
+    if (hipGetDevice(&c->device) != hipSuccess) { mkb_rows_comm_destroy(c); return set_error(MKB_ERR_HIP, "hipGetDevice failed"); }
+    if (int rc = comm_alloc(c)) { mkb_rows_comm_destroy(c); return rc; }
+    *out = c;
+    return MKB_OK;
+}
+
 extern "C" int mkb_rows_comm_create(const uint8_t *id_host, int rank, int world, int64_t max_requests, mkb_rows_comm_t **out) {
     MKB_REQUIRE(id_host && out, "null pointer");
     MKB_REQUIRE(world >= 1 && world <= kCommMaxWorld && rank >= 0 && rank < world, "bad rank / world (at most %d ranks)", kCommMaxWorld);
@@ -229,17 +478,7 @@ extern "C" int mkb_rows_comm_create(const uint8_t *id_host, int rank, int world,
     if (rccl().CommInitRank(&c->plan_comm, world, ids[0], rank) != ncclSuccess ||
         rccl().CommInitRank(&c->step_comm, world, ids[1], rank) != ncclSuccess)
         return fail(set_error(MKB_ERR_HIP, "ncclCommInitRank failed (rank %d of %d)", rank, world));
-    const size_t block_bytes = sizeof(int64_t) * (size_t)world * (size_t)(1 + c->cap);
-    for (int s = 0; s < kCommSlots; ++s) {
-        if (hipMalloc(&c->send_block[s], block_bytes) != hipSuccess || hipMalloc(&c->recv_block[s], block_bytes) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ready[s], hipEventDisableTiming) != hipSuccess)
-            return fail(set_error(MKB_ERR_HIP, "allocation failed in mkb_rows_comm_create"));
-    }
-    if (hipEventCreateWithFlags(&c->after, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&c->mail_host), sizeof(Mailbox) * kCommSlots, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void **>(&c->mail_dev), c->mail_host, 0) != hipSuccess)
-        return fail(set_error(MKB_ERR_HIP, "mailbox allocation failed in mkb_rows_comm_create"));
-    memset(c->mail_host, 0, sizeof(Mailbox) * kCommSlots);
+    if (int rc = comm_alloc(c)) return fail(rc);
     *out = c;
     return MKB_OK;
 }
@@ -260,12 +499,19 @@ extern "C" int mkb_rows_comm_plan(mkb_rows_comm_t *c, int slot, const int64_t *s
     if (int rc = mkb_rows_route(sample, b, 1, c->world, row0, send_ids, slot_of, counts, compact, bad, side_stream)) return rc;
     if (int rc = mkb_rows_blocks_pack(counts, send_ids, c->send_block[slot], c->world, c->cap, side_stream)) return rc;
     const size_t n = (size_t)(1 + c->cap);
-    MKB_CHECK_NCCL(rccl().GroupStart());
+    if (int rc = t_group_start(c)) return rc;
     for (int p = 0; p < c->world; ++p) {
-        MKB_CHECK_NCCL(rccl().Send(c->send_block[slot] + p * n, n, ncclInt64, p, c->plan_comm, side));
-        MKB_CHECK_NCCL(rccl().Recv(c->recv_block[slot] + p * n, n, ncclInt64, p, c->plan_comm, side));
+        int rc = t_op(c, 0, c->send_block[slot] + p * n, n, ncclInt64, p, 0, side);
+        if (!rc) rc = t_op(c, 1, c->recv_block[slot] + p * n, n, ncclInt64, p, 0, side);
+        if (rc) {  // close the group that was opened (RCCL keeps the group state per thread), keep the first error's message
+            char msg[512];
+            snprintf(msg, sizeof(msg), "%s", mkb_last_error());
+            c->pending.clear();
+            (void)t_group_end(c);
+            return set_error(rc, "%s", msg);
+        }
     }
-    MKB_CHECK_NCCL(rccl().GroupEnd());
+    if (int rc = t_group_end(c)) return rc;
     c->seq_of[slot] = ++c->plans;
     if (int rc = mkb_rows_blocks_unpack(c->recv_block[slot], counts, want, want_cap, c->mail_dev + slot, c->seq_of[slot], bad, c->world,
                                         c->cap, side_stream)) return rc;
@@ -286,11 +532,13 @@ extern "C" int mkb_rows_comm_take(mkb_rows_comm_t *c, int slot, int64_t *sent_ho
         (void)hipGetLastError();
         timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
+        double limit_s = 120.0;  // MKB_ROWS_TAKE_TIMEOUT_S (read per call: the test of this path sets a short one)
+        if (const char *e = getenv("MKB_ROWS_TAKE_TIMEOUT_S")) { const double v = atof(e); if (v > 0) limit_s = v; }
         for (uint64_t spins = 0; __atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
             if ((spins & 0xFFF) == 0xFFF) {
                 clock_gettime(CLOCK_MONOTONIC, &t1);
-                if (t1.tv_sec - t0.tv_sec > 120)
-                    return set_error(MKB_ERR_HIP, "mkb_rows_comm_take: the plan in slot %d did not complete within 120 s (a peer that never planned this batch?)", slot);
+                if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit_s)
+                    return set_error(MKB_ERR_HIP, "mkb_rows_comm_take: the plan in slot %d did not complete within %.1f s (a peer that never planned this batch?)", slot, limit_s);
             }
             __builtin_ia32_pause();
         }
@@ -313,26 +561,30 @@ extern "C" int mkb_rows_comm_exchange(mkb_rows_comm_t *c, float *reduce, int64_t
     static const bool one_group_env = getenv("MKB_ROWS_ONE_GROUP") && getenv("MKB_ROWS_ONE_GROUP")[0] == '1';
     const bool one_group = one_group_env || c->world == 1;
     if (!one_group && reduce_n > 0)
-        MKB_CHECK_NCCL(rccl().AllReduce(reduce, reduce, (size_t)reduce_n, ncclFloat32, ncclSum, c->step_comm, st));
-    MKB_CHECK_NCCL(rccl().GroupStart());
+        if (int rc = t_op(c, 2, reduce, (size_t)reduce_n, ncclFloat32, 0, 1, st)) return rc;
+    if (int rc = t_group_start(c)) return rc;
+    auto bail = [&](int rc) {  // close the group that was opened (RCCL keeps the group state per thread), keep the first error's message
+        char msg[512];
+        snprintf(msg, sizeof(msg), "%s", mkb_last_error());
+        c->pending.clear();
+        (void)t_group_end(c);
+        return set_error(rc, "%s", msg);
+    };
     if (one_group && reduce_n > 0)
-        MKB_CHECK_NCCL(rccl().AllReduce(reduce, reduce, (size_t)reduce_n, ncclFloat32, ncclSum, c->step_comm, st));
+        if (int rc = t_op(c, 2, reduce, (size_t)reduce_n, ncclFloat32, 0, 1, st)) return bail(rc);
     if (send_rows_host && recv_rows_host) {
         int64_t so = 0, ro = 0;
         for (int p = 0; p < c->world; ++p) {
             const int64_t ns = send_rows_host[p], nr = recv_rows_host[p];
-            if (ns < 0 || nr < 0 || (ns > 0 && !send) || (nr > 0 && !recv)) {
-                (void)rccl().GroupEnd();
-                return set_error(MKB_ERR_INVALID, "bad row counts / null row buffer in mkb_rows_comm_exchange");
-            }
-            if (ns > 0) MKB_CHECK_NCCL(rccl().Send(send + so * D, (size_t)(ns * D), ncclFloat32, p, c->step_comm, st));
-            if (nr > 0) MKB_CHECK_NCCL(rccl().Recv(recv + ro * D, (size_t)(nr * D), ncclFloat32, p, c->step_comm, st));
+            if (ns < 0 || nr < 0 || (ns > 0 && !send) || (nr > 0 && !recv))
+                return bail(set_error(MKB_ERR_INVALID, "bad row counts / null row buffer in mkb_rows_comm_exchange"));
+            if (ns > 0) if (int rc = t_op(c, 0, const_cast<float *>(send) + so * D, (size_t)(ns * D), ncclFloat32, p, 1, st)) return bail(rc);
+            if (nr > 0) if (int rc = t_op(c, 1, recv + ro * D, (size_t)(nr * D), ncclFloat32, p, 1, st)) return bail(rc);
             so += ns;
             ro += nr;
         }
     }
-    MKB_CHECK_NCCL(rccl().GroupEnd());
-    return MKB_OK;
+    return t_group_end(c);
 }
 
 extern "C" int mkb_rows_comm_stats(mkb_rows_comm_t *c, int64_t *plans, int64_t *takes_that_waited, int64_t *waited_with_idle_stream) {

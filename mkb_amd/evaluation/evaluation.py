@@ -61,14 +61,18 @@ class Evaluation:
             self._keys_cache = cache
         return cache[1]
 
-    def ranks(self, model, dataset, mode, chunk=1024):
-        """Filtered rank (1-based) of every triple of ``dataset`` in ``mode``, computed on the device: int64 tensor."""
+    def ranks(self, model, dataset, mode, chunk=1024, with_scores=False):
+        """Filtered rank (1-based) of every triple of ``dataset`` in ``mode``, computed on the device: int64 tensor.
+        ``with_scores=True`` -> ``(ranks, scores [n, n_entity])``: the scores of every triple against all entities the ranks
+        were counted on (``mkb_rank_scores``; what ``model(sample, all entities, mode)`` returns at evaluation.py:237, before the
+        filter bias)."""
         dev = model.entity_embedding.device
         _hip.require_device(model.entity_embedding)
         model.sync_parameters()
         keys = self._true_keys(dev, model.n_entity, model.n_relation)[mode]
         triples = torch.as_tensor(np.asarray(dataset, dtype=np.int64).reshape(-1, 3), device=dev)
         out = torch.empty(len(triples), dtype=torch.int64, device=dev)
+        scores = torch.empty((len(triples), model.n_entity), dtype=torch.float32, device=dev) if with_scores else None
         lib, tb = _hip.lib(), model._tables()
         ws = None
         with _hip.on_device(dev):
@@ -78,11 +82,17 @@ class Evaluation:
                 if ws is None or ws.numel() < need + 256:
                     ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
                 off = (-ws.data_ptr()) % 256
+                if with_scores:
+                    _hip.check(lib.mkb_rank_scores(tb, _hip.ptr(s), s.shape[0], _hip.mode_id(mode), _hip.ptr(keys), keys.numel(),
+                                                   _hip.ptr(out[lo: lo + chunk]), _hip.ptr(scores[lo: lo + chunk]),
+                                                   ctypes.c_void_p(ws.data_ptr() + off), need, _hip.stream_ptr()),
+                               "mkb_rank_scores")
+                    continue
                 _hip.check(lib.mkb_rank(tb, _hip.ptr(s), s.shape[0], _hip.mode_id(mode), _hip.ptr(keys), keys.numel(),
                                         _hip.ptr(out[lo: lo + chunk]), ctypes.c_void_p(ws.data_ptr() + off), need,
                                         _hip.stream_ptr()),
                            "mkb_rank")
-        return out
+        return (out, scores) if with_scores else out
 
     def _device_ok(self, model):
         units = model.hidden_dim if model.name == "RotatE" else model.entity_dim

@@ -460,37 +460,44 @@ def test_out_of_range_ids_raise_index_error_like_index_select():
     torch.cuda.synchronize()
 
 
-def test_score_functions_of_one_backward_pass_share_their_dense_gradient_buffer(monkeypatch):
-    """README-style step (positive scores and negative scores from two ``model(...)`` calls, one ``loss.backward()``): the two
-    backward functions share ONE dense gradient buffer per table (mkb_amd/_gradshare.py: the second accumulates into the first
-    one's tensor and returns None to autograd).  The gradients must equal those of the unshared form (every function its own
-    zero-filled buffer, the autograd engine adds them), and a second backward pass must start from fresh buffers."""
-    from mkb_amd import _gradshare, datasets, losses, models, sampling
+@pytest.mark.parametrize("optimizer", ["torch", "row-lazy"])
+def test_table_gradients_with_a_regulariser_on_both_tables(optimizer):
+    """README-style step (positive and negative scores from two ``model(...)`` calls, one ``loss.backward()``) with a norm
+    regulariser on BOTH tables in the same graph -- a third and fourth contributor to the tables' gradients besides the two score
+    functions.  ``.grad`` must be scores' gradient + regulariser's gradient on every row (round 5's shared buffer lost the rows of
+    whichever score function ran its backward after the engine had summed the first one's buffer with the regulariser's).  Both
+    gradient routes: dense buffers handed to autograd (torch.optim) and rows added straight into ``.grad`` (row-lazy Adam); two
+    passes without zero_grad in between, so ``.grad`` accumulates."""
+    from mkb_amd import datasets, losses, models, optim, sampling
 
     ds = datasets.Umls(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
     s, w = train[:64].contiguous(), (torch.rand(64) + 0.1).cuda()
     crit = losses.Adversarial(alpha=0.5)
 
-    def grads(shared, name):
+    def grads(name, reg):
         torch.manual_seed(3)
         m = getattr(models, name)(hidden_dim=20, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
         ns = sampling.NegativeSampling(size=8, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=4)
-        if not shared:
-            monkeypatch.setattr(_gradshare, "_task", None)
+        if optimizer == "row-lazy":
+            opt = optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3, lazy_rows=True)  # noqa: F841 (owns the tables)
         out = []
-        for mode in ("head-batch", "tail-batch"):  # two backward passes without zero_grad in between: .grad accumulates
+        for mode in ("head-batch", "tail-batch"):
             neg = ns.generate(s, mode)
-            crit(m(s), m(s, neg, mode), w).backward()
-            out.append((m.entity_embedding.grad.clone(), m.relation_embedding.grad.clone()))
-        monkeypatch.undo()
+            loss = crit(m(s), m(s, neg, mode), w)
+            if reg:
+                loss = loss + 1e-3 * (m.entity_embedding ** 2).sum() + 1e-3 * (m.relation_embedding.abs() ** 3).sum()
+            loss.backward()
+            out.append((m.entity_embedding.grad.clone(), m.relation_embedding.grad.clone(),
+                        m.entity_embedding.detach().clone(), m.relation_embedding.detach().clone()))
         return out
 
-    for name in ("RotatE", "TransE", "pRotatE"):
-        a, b = grads(True, name), grads(False, name)
-        for (ea, ra), (eb, rb) in zip(a, b):
-            np.testing.assert_allclose(ea.cpu().numpy(), eb.cpu().numpy(), rtol=0, atol=2e-7)
-            np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), rtol=0, atol=2e-6)
+    for name in ("RotatE", "TransE", "pRotatE", "ComplEx"):
+        a, b = grads(name, True), grads(name, False)
+        for k, ((ea, ra, e, r), (eb, rb, _, _)) in enumerate(zip(a, b)):
+            reg_e, reg_r = (k + 1) * 2e-3 * e, (k + 1) * 3e-3 * r * r.abs()  # (accumulated over k + 1 passes; tables do not move)
+            np.testing.assert_allclose(ea.cpu().numpy(), (eb + reg_e).cpu().numpy(), rtol=0, atol=3e-7)
+            np.testing.assert_allclose(ra.cpu().numpy(), (rb + reg_r).cpu().numpy(), rtol=0, atol=2e-6)
 
 
 def test_multi_tensor_dense_adam_equals_one_launch_per_tensor_bit_for_bit():

@@ -1,0 +1,238 @@
+"""-m gpu: the library-issued collectives of the row-sharded step (mkb_rows_comm_plan / _take / _exchange, mkb_amd/csrc/rows_comm.hip)
+driven for world in {2, 3, 8} in ONE process on ONE device: every rank is a host thread with its own step and side streams, the
+communicators sit on the in-process transport (mkb_rows_comm_create_loopback) because RCCL refuses two ranks on one device.  No
+reference counterpart (mkb is single-process).
+
+Per step and rank, exactly the calls mkb_amd/table_rows.py makes: plan two batches AHEAD on the side stream, take (split sizes
+through the host-coherent mailbox), exchange #1 (pool block all-reduce + positive rows owner -> requester), exchange #2 (gradient
+block all-reduce + gradient rows requester -> owner).  Ten steps: the four plan slots and their mailbox sequence numbers wrap
+twice.  Every payload is checked against what the protocol promises, computed from the full table the test holds:
+  * forward: requester r receives, for each owner p, the rows of exactly the ids of its route's group p, in that order;
+  * all-reduces: the sum over ranks, identical bits on every rank (contributions are added in rank order);
+  * backward: owner p receives, requester after requester, the gradient rows of exactly the shard indices in its `want` list.
+A rank that never plans, or a split size two ranks disagree on, must come back as an ERROR (time-out / size check), never a hang.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+D, N_ENT, P_POOL, STEPS, AHEAD = 48, 5003, 40, 10, 2
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _Rank:
+    """One rank of the in-process world: its communicator, its streams, its ring of plan buffers."""
+
+    def __init__(self, hub, rank, world, b, full):
+        from mkb_amd import _hip
+
+        self.lib, self._hip = _hip.lib(), _hip
+        self.rank, self.world, self.b = rank, world, b
+        self.dev = torch.device("cuda", 0)
+        self.full = full                                   # [N, D] on the device (every thread reads it; nobody writes)
+        self.shard = full[rank::world].contiguous()
+        h = ctypes.c_void_p()
+        _hip.check(self.lib.mkb_rows_comm_create_loopback(hub, rank, 2 * b, ctypes.byref(h)), "mkb_rows_comm_create_loopback")
+        self.h = h
+        self.step_stream, self.side = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+        cap = 2 * b * world
+        self.ring = [dict(send_ids=torch.empty(2 * b, dtype=torch.int64, device=self.dev), slot=torch.empty(2 * b, dtype=torch.int32, device=self.dev),
+                          counts=torch.empty(world, dtype=torch.int64, device=self.dev), compact=torch.empty((b, 3), dtype=torch.int64, device=self.dev),
+                          want=torch.empty(cap, dtype=torch.int64, device=self.dev)) for _ in range(4)]
+        self.bad = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.I64 = ctypes.c_int64 * world
+
+    def plan(self, t, sample):
+        r = self.ring[t % 4]
+        self._hip.check(self.lib.mkb_rows_comm_plan(self.h, t % 4, _ptr(sample), self.b, P_POOL + 1, _ptr(r["send_ids"]), _ptr(r["slot"]),
+                                                    _ptr(r["counts"]), _ptr(r["compact"]), _ptr(r["want"]), r["want"].numel(), _ptr(self.bad),
+                                                    ctypes.c_void_p(self.step_stream.cuda_stream), ctypes.c_void_p(self.side.cuda_stream)),
+                        "mkb_rows_comm_plan")
+
+    def take(self, t):
+        sent, wanted = self.I64(), self.I64()
+        self._hip.check(self.lib.mkb_rows_comm_take(self.h, t % 4, sent, wanted, ctypes.c_void_p(self.step_stream.cuda_stream)), "mkb_rows_comm_take")
+        return list(sent), list(wanted)
+
+    def exchange(self, reduce, send, send_rows, recv, recv_rows):
+        self._hip.check(self.lib.mkb_rows_comm_exchange(self.h, _ptr(reduce), 0 if reduce is None else reduce.numel(), _ptr(send),
+                                                        self.I64(*send_rows), _ptr(recv), self.I64(*recv_rows), D,
+                                                        ctypes.c_void_p(self.step_stream.cuda_stream)), "mkb_rows_comm_exchange")
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.lib.mkb_rows_comm_destroy(self.h)
+
+
+def _batches(world, b, seed):
+    """sample[t][r]: [b, 3] int64 triples of rank r at step t (a hub entity requested by every rank; duplicates inside a batch)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for t in range(STEPS + AHEAD):
+        per = []
+        for r in range(world):
+            s = np.stack([rs.randint(N_ENT, size=b), rs.randint(7, size=b), rs.randint(N_ENT, size=b)], 1).astype(np.int64)
+            s[: max(1, b // 4), 0] = 17            # a hot head: merged into one request, one owner gets it from everybody
+            s[-1, 2] = s[0, 2]                     # a duplicated tail
+            per.append(s)
+        out.append(per)
+    return out
+
+
+def _grad_value(rank, step, gid):
+    """The gradient row requester `rank` returns for entity gid at `step` (any function the owner can recompute)."""
+    return ((rank + 1) * 0.5 + step * 0.125 + (gid % 997) * 0.001).to(torch.float32)
+
+
+def _run_rank(R, batches, pool_ids, errors, barrier):
+    try:
+        torch.cuda.set_device(0)
+        world, rank, b = R.world, R.rank, R.b
+        col = torch.arange(D, device=R.dev, dtype=torch.float32) * 0.01 + 1.0
+        samples = [torch.as_tensor(batches[t][rank], device=R.dev) for t in range(STEPS + AHEAD)]
+        torch.cuda.synchronize()
+        barrier.wait()
+        with torch.cuda.stream(R.step_stream):
+            for t in range(AHEAD):
+                R.plan(t, samples[t])
+            for t in range(STEPS):
+                R.plan(t + AHEAD, samples[t + AHEAD])             # two batches ahead: slots t % 4 .. (t + 2) % 4 are in flight
+                sent, wanted = R.take(t)
+                ring = R.ring[t % 4]
+                n_sent, n_want = sum(sent), sum(wanted)
+                # ---- forward: owners read the requested rows; the pool block is completed by the all-reduce
+                want = ring["want"][:n_want]
+                rows_out = R.shard[want]                           # (take made this stream wait for the plan)
+                pool = pool_ids[t]
+                mine = (pool % world) == rank
+                block = torch.zeros((P_POOL + 1, D), device=R.dev)
+                block[:P_POOL][mine] = R.full[pool[mine]]
+                block[P_POOL, 0] = float(rank + 1)                 # the weight-sum slot: 1 + 2 + ... + world
+                got = torch.full((max(n_sent, 1), D), float("nan"), device=R.dev)
+                R.exchange(block, rows_out, wanted, got, sent)
+                send_ids = ring["send_ids"]
+                owner = torch.repeat_interleave(torch.arange(world, device=R.dev), torch.as_tensor(sent, device=R.dev))
+                gids = send_ids[:n_sent] * world + owner           # group p of send_ids = shard indices on owner p
+                assert torch.equal(got[:n_sent], R.full[gids]), f"rank {rank} step {t}: positive rows"
+                assert torch.equal(block[:P_POOL], R.full[pool]), f"rank {rank} step {t}: pool block"
+                assert block[P_POOL, 0].item() == world * (world + 1) / 2
+                # every request of the batch is answered: slot_of maps the 2 b requests onto the received rows
+                req = torch.cat([samples[t][:, 0], samples[t][:, 2]])  # (sample layout: heads then tails)
+                slot_of = ring["slot"].long()
+                assert torch.equal(gids[slot_of], req) or torch.equal(gids[slot_of], samples[t][:, [0, 2]].reshape(-1)), f"rank {rank} step {t}: slots"
+                # ---- backward: gradient rows go home, the shared block is summed
+                g_rows = _grad_value(rank, t, gids)[:, None] * col[None, :]
+                gblock = torch.full((P_POOL + 1, D), float(rank) + 0.25, device=R.dev)
+                back = torch.full((max(n_want, 1), D), float("nan"), device=R.dev)
+                R.exchange(gblock, g_rows.contiguous(), sent, back, wanted)
+                requester = torch.repeat_interleave(torch.arange(world, device=R.dev), torch.as_tensor(wanted, device=R.dev))
+                expect = _grad_value(requester, t, want * world + rank)[:, None] * col[None, :]
+                assert torch.equal(back[:n_want], expect), f"rank {rank} step {t}: gradient rows"
+                assert torch.equal(gblock, torch.full_like(gblock, sum(float(q) + 0.25 for q in range(world)))), f"rank {rank} step {t}: gradient block"
+        torch.cuda.synchronize()
+        assert int(R.bad.item()) == 0
+    except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+        errors.append((R.rank, repr(e)))
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+
+
+@pytest.mark.parametrize("world,b", [(2, 64), (3, 33), (8, 16), (8, 128)])
+def test_plan_take_exchange_over_the_loopback_transport(world, b, monkeypatch):
+    from mkb_amd import _hip
+
+    monkeypatch.setenv("MKB_ROWS_LOOP_TIMEOUT_S", "30")
+    lib = _hip.lib()
+    torch.manual_seed(world * 100 + b)
+    full = torch.randn(N_ENT, D, device="cuda")
+    batches = _batches(world, b, seed=world + b)
+    rs = np.random.RandomState(5)
+    pool_ids = [torch.as_tensor(rs.randint(N_ENT, size=P_POOL), device="cuda") for _ in range(STEPS)]
+    hub = ctypes.c_void_p()
+    _hip.check(lib.mkb_rows_loop_hub_create(world, ctypes.byref(hub)), "mkb_rows_loop_hub_create")
+    ranks = [_Rank(hub, r, world, b, full) for r in range(world)]
+    errors, barrier = [], threading.Barrier(world)
+    threads = [threading.Thread(target=_run_rank, args=(R, batches, pool_ids, errors, barrier)) for R in ranks]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    alive = [th.is_alive() for th in threads]
+    assert not any(alive), f"ranks still running (hang): {alive}; errors so far: {errors}"
+    assert not errors, errors
+    plans = ctypes.c_int64()
+    a, c = ctypes.c_int64(), ctypes.c_int64()
+    for R in ranks:
+        _hip.check(lib.mkb_rows_comm_stats(R.h, ctypes.byref(plans), ctypes.byref(a), ctypes.byref(c)), "mkb_rows_comm_stats")
+        assert plans.value == STEPS + AHEAD
+        R.close()
+    lib.mkb_rows_loop_hub_destroy(hub)
+
+
+def test_take_times_out_with_an_error_when_the_plan_never_executes(monkeypatch):
+    """A plan whose side stream is stuck (here: behind a long sleep kernel; across GPUs: a peer that never planned the batch)
+    must make take() return an error after MKB_ROWS_TAKE_TIMEOUT_S, not spin for ever."""
+    from mkb_amd import _hip
+
+    lib = _hip.lib()
+    hub = ctypes.c_void_p()
+    _hip.check(lib.mkb_rows_loop_hub_create(1, ctypes.byref(hub)), "mkb_rows_loop_hub_create")
+    R = _Rank(hub, 0, 1, 8, torch.randn(N_ENT, D, device="cuda"))
+    sample = torch.as_tensor(_batches(1, 8, 1)[0][0], device="cuda")
+    with torch.cuda.stream(R.side):
+        torch.cuda._sleep(int(4e9))  # ~2 s of device time in front of the plan
+    monkeypatch.setenv("MKB_ROWS_TAKE_TIMEOUT_S", "0.2")
+    R.plan(0, sample)
+    with pytest.raises(_hip.HipLibraryError, match="did not complete within"):
+        R.take(0)
+    monkeypatch.setenv("MKB_ROWS_TAKE_TIMEOUT_S", "30")
+    sent, wanted = R.take(0)  # ... and the plan is still good once it has run
+    assert sum(sent) == sum(wanted) > 0
+    R.close()
+    lib.mkb_rows_loop_hub_destroy(hub)
+
+
+def test_disagreeing_split_sizes_and_missing_peers_are_errors_not_hangs(monkeypatch):
+    """World 2: (a) rank 1 never joins an exchange -> rank 0's call returns an error after the hub's time-out; (b) the two ranks
+    disagree about a row count -> the receiver is told (over RCCL this is a hang or silent corruption)."""
+    from mkb_amd import _hip
+
+    monkeypatch.setenv("MKB_ROWS_LOOP_TIMEOUT_S", "1.5")
+    lib = _hip.lib()
+    hub = ctypes.c_void_p()
+    _hip.check(lib.mkb_rows_loop_hub_create(2, ctypes.byref(hub)), "mkb_rows_loop_hub_create")
+    full = torch.randn(N_ENT, D, device="cuda")
+    R0, R1 = _Rank(hub, 0, 2, 8, full), _Rank(hub, 1, 2, 8, full)
+    rows = torch.ones((4, D), device="cuda")
+    got = torch.empty((4, D), device="cuda")
+    with pytest.raises(_hip.HipLibraryError, match="never"):
+        R0.exchange(None, rows, [0, 2], got, [0, 2])  # rank 1 makes no call at all
+    out = {}
+
+    def second():
+        try:
+            R1.exchange(None, rows, [3, 0], got.clone(), [2, 0])  # sends 3 rows to rank 0 ...
+        except Exception as e:  # noqa: BLE001
+            out["r1"] = repr(e)
+
+    th = threading.Thread(target=second)
+    th.start()
+    try:
+        R0.exchange(None, rows, [0, 2], got, [0, 2])              # ... which expects 2 from rank 1
+    except Exception as e:  # noqa: BLE001
+        out["r0"] = repr(e)
+    th.join(timeout=60)
+    assert not th.is_alive()
+    assert "split sizes disagree" in out.get("r0", "") or "split sizes disagree" in out.get("r1", ""), out
+    torch.cuda.synchronize()

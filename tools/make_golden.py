@@ -350,6 +350,48 @@ def gen_headline_slice():
     np.savez_compressed(OUT / "headline_slice.npz", **out)
 
 
+def gen_eval_headline():
+    """Filtered ranking at the headline size from the LIVE reference: FB15k-237, hidden 1000, all five models, 8 test triples x both
+    sides, each against all 14,541 entities -- ``datasets.base.TestDataset`` items (base.py:196-241) collated and ranked by the
+    arithmetic of ``Evaluation.compute_score`` (evaluation.py:232-263).  Stored per (model, mode): the ranks, the biased scores of
+    every 16th column, the unbiased score of the target; tables come from tests/util_gpu_tables.py::eval_tables (numpy legacy
+    generator), so the fixture holds no table."""
+    sys.path.insert(0, str(OUT.parent))
+    from util_gpu_tables import eval_tables
+    from mkb.datasets import base as ref_base
+
+    ds = datasets.Fb15k237(batch_size=8, shuffle=False, seed=42)
+    test = np.asarray(ds.test, dtype=np.int64)
+    idx = np.random.RandomState(11).choice(len(test), size=8, replace=False)
+    out = {"idx": idx.astype(np.int32), "table_seed": np.int32(77), "gamma": np.float32(9.0), "hidden": np.int32(1000),
+           "column_stride": np.int32(16)}
+    triples = [tuple(int(v) for v in test[i]) for i in idx]
+    for name in MODELS:
+        ent, rel, modulus = eval_tables(name, seed=77)
+        m = getattr(models, name)(hidden_dim=1000, entities=ds.entities, relations=ds.relations, gamma=9).eval()
+        with torch.no_grad():
+            m.entity_embedding.copy_(torch.from_numpy(ent))
+            m.relation_embedding.copy_(torch.from_numpy(rel))
+            if modulus is not None:
+                assert np.array_equal(npy(m.modulus), modulus), (npy(m.modulus), modulus)
+        for mode in ["head-batch", "tail-batch"]:
+            td = ref_base.TestDataset(triples=triples, true_triples=ds.true_triples, entities=ds.entities, relations=ds.relations,
+                                      mode=mode)
+            data = ref_base.TestDataset.collate_fn([td[i] for i in range(len(triples))])
+            with torch.no_grad():
+                score = m(sample=data["sample"], negative_sample=data["negative_sample"], mode=mode)
+                target = data["sample"][:, 0] if mode == "head-batch" else data["sample"][:, 2]
+                out[f"{name}/{mode}/target_score"] = npy(score[torch.arange(len(triples)), target])
+                score += data["filter_bias"]
+                argsort = torch.argsort(score, dim=1, descending=True)
+                ranks = [1 + (argsort[i, :] == target[i]).nonzero().item() for i in range(len(triples))]
+            out[f"{name}/{mode}/ranks"] = np.asarray(ranks, dtype=np.int64)
+            out[f"{name}/{mode}/biased_scores_every_16th"] = npy(score[:, ::16])
+            out[f"{name}/{mode}/n_filtered"] = npy((data["filter_bias"] != 0).sum(dim=1)).astype(np.int32)
+            print(name, mode, ranks, file=sys.stderr)
+    np.savez_compressed(OUT / "eval_headline.npz", **out)
+
+
 def gen_distill():
     """Distillation (distillation/distillation.py:438-683, kdmkb_model.py:286-360) captured from the live reference:
     (a) KlDivergence values + student gradients on random score matrices; (b) Distillation.distill with UniformSampling on
@@ -434,7 +476,7 @@ def gen_distill():
 
 if __name__ == "__main__":
     OUT.mkdir(parents=True, exist_ok=True)
-    which = sys.argv[1:] or ["models", "init", "sampler", "weights", "pipeline", "eval", "headline_slice", "distill"]
+    which = sys.argv[1:] or ["models", "init", "sampler", "weights", "pipeline", "eval", "headline_slice", "distill", "eval_headline"]
     for w in which:
         print("generating", w, file=sys.stderr)
         globals()[f"gen_{w}"]()
