@@ -114,8 +114,13 @@ __device__ __forceinline__ void pair_bwd_real(float q, float x, float g, float k
         // d|z| / dz = sign(z) in {-1, 0, 1} (torch's abs backward: 0 at the origin).  As a SIGNED-INTEGER median of z's bit
         // pattern: positive floats are positive integers, negative floats negative ones, +0 is 0 -- one v_med3_i32 and a
         // conversion instead of two compare / select pairs (the pair term is a sign and two adds: round 4's pooled TransE
-        // backward spent 7 VALU operations per element, 5 now).  (-0 would read as negative; a sum or difference of finite
-        // numbers is +0 when it is zero, except (-0) + (-0).)
+        // backward spent 7 VALU operations per element, 5 now).
+        // ACCEPTED DEVIATIONS from torch's abs backward at two edge values: z = -0 reads as negative (sign -1 where torch
+        // gives 0) -- a sum or difference of finite numbers is +0 when it is zero EXCEPT (-0) + (-0) and (-0) - (+0), i.e. only when
+        // a table entry is itself a negative zero, which the reference's uniform_ initialisation and Adam updates do not produce; and
+        // z = NaN gives +-1 instead of propagating NaN into this element's gradient (the loss is NaN then anyway: bench.py and
+        // Pipeline stop on a non-finite loss).  Canonicalising with z + 0.0f would cost a sixth VALU operation per element in a
+        // kernel bound by exactly that count.
         const float z = HEAD ? (x + q) : (q - x);
         int si;  // (written as min(max(zi, -1), 1) the compiler emits two compare / select pairs again)
         asm("v_med3_i32 %0, %1, -1, 1" : "=v"(si) : "v"(__float_as_uint(z)));

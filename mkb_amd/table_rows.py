@@ -101,11 +101,17 @@ class RowsComm:
 
     def plan(self, slot, sample, row0, bufs, bad):
         b = sample.shape[0]
+        # MKB_ROWS_PLAN_ON_STEP_STREAM=1: the plan's id exchange is queued on the STEP's stream instead of the side stream, so the two
+        # communicators never have a kernel in flight at the same time on a device.  The default (side stream) lets the plan of batch
+        # t + 2 run beside step t; two RCCL communicators progressing concurrently on every device is something this code could only
+        # exercise at world 1 and over the in-process transport (tests/test_gpu_rows_loopback.py) -- the switch is the fallback for a
+        # node where ranks were seen to schedule the two in different orders and stall.
+        side = _hip.stream_ptr(self.device) if os.environ.get("MKB_ROWS_PLAN_ON_STEP_STREAM", "0") == "1" else self.side.cuda_stream
         with _hip.on_device(self.device):
             _hip.check(_hip.lib().mkb_rows_comm_plan(self._handle, slot, _hip.ptr(sample), b, row0, _hip.ptr(bufs["send_ids"]),
                                                      _hip.ptr(bufs["slot"]), _hip.ptr(bufs["counts"]), _hip.ptr(bufs["compact"]),
                                                      _hip.ptr(bufs["want"]), bufs["want"].numel(), _hip.ptr(bad),
-                                                     _hip.stream_ptr(self.device), self.side.cuda_stream), "mkb_rows_comm_plan")
+                                                     _hip.stream_ptr(self.device), side), "mkb_rows_comm_plan")
 
     def take(self, slot):
         sent, wanted = self._I64(), self._I64()

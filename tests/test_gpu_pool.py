@@ -211,7 +211,11 @@ def test_headline_full_size_every_row_weighted_vs_oracle(name, mode):
     modes (rotate.py:83-97, complex.py:65-85, distmult.py:63-75, transe.py:65-76 -- ComplEx / DistMult run on the matrix
     route, whose row clamp once hid in the last three batch rows).  The oracle walks the batch in 8 chunks of 128 rows
     (memory: [128, 256, 2000] per chunk) -- the loss is a weighted sum over rows with the global normaliser W
-    (adversarial.py:28-29), so the chunks' results, each rescaled by W_chunk / W, add up to the step of the whole batch."""
+    (adversarial.py:28-29), so the chunks' results, each rescaled by W_chunk / W, add up to the step of the whole batch.
+    RotatE's oracle runs with ``fast_norm=True`` here: sqrt(re^2 + im^2) instead of the reference's stack -> norm(dim=0)
+    (rotate.py:95-96; a torch-CPU pathology, ~50x slower) -- ~1 ulp per term apart, far inside the 1e-4 of this test; the
+    reference-exact form is held on the 128-row tests/golden/headline_slice.npz (test_headline_slice_vs_reference_golden) and
+    the two oracle forms against each other in tests/test_oracle_scoring.py."""
     from mkb_amd import datasets, models, sampling
     from mkb_amd.fused import FusedTrainStep
     from oracle import scoring
