@@ -412,6 +412,8 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
     from mkb_amd import _hip
 
     globals().update(CONFIGS[config])
+    if os.environ.get("MKB_BENCH_LR"):  # diagnostic (e.g. 0: the tables never move): not a benchmark setting
+        globals()["LR"] = float(os.environ["MKB_BENCH_LR"])
     ctx = build(device, rank, world, parallelism=parallelism, force=force)
     ctx["rows_per_rank"] = B if (args.scaling == "weak" or world == 1) else max(8, B // world)
     if world > 1 and not ctx["dims"] and not ctx["trows"]:
@@ -426,6 +428,15 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         torch.cuda.synchronize()
 
     kinds = ["pool_fwd", "pool_bwd_q", "pool_bwd_x", "adam", "sampler", "loss", "general_fwd", "general_bwd"]
+    if getattr(args, "preheat_ms", 0.0) > 0:
+        a_ = torch.randn(4096, 4096, device=device)
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        while (time.perf_counter() - t_) * 1e3 < args.preheat_ms:
+            for _ in range(8):
+                a_ @ a_
+            torch.cuda.synchronize()
+        del a_
     for i in range(warmup):
         run_step(ctx, i)
     barrier()
@@ -686,9 +697,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--windows", type=int, default=int(os.environ.get("MKB_BENCH_WINDOWS", "7")),
+    ap.add_argument("--windows", type=int, default=int(os.environ.get("MKB_BENCH_WINDOWS", "15")),
                     help="timed windows of --steps steps each, back to back, every one between barriers; ms_per_step / value are "
                          "the MEDIAN window and all of them are printed (windows_ms)")
+    ap.add_argument("--preheat-ms", type=float, default=0.0,
+                    help="diagnostic: keep the device busy with unrelated torch matmuls for that long right before the warm-up steps "
+                         "(tells a clock / power ramp of the device from a warm-up effect of this code's own state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="rows of the cpu_baseline sample (reference-faithful form)")
     ap.add_argument("--no-variants", action="store_true", help="skip the with/without optimizer & sampler step variants")

@@ -833,6 +833,9 @@ __global__ __launch_bounds__(64) void pool_bwd_wave_kernel(PoolArgs A) {
 #ifndef MKB_HANDON_PRIO
 #define MKB_HANDON_PRIO 0
 #endif
+#ifndef MKB_BWD1_Q_EARLY
+#define MKB_BWD1_Q_EARLY 1
+#endif
 constexpr int kBwd1Waves = 16;
 constexpr int kChunkStride = 1;                         // chunks (= phases) between a wave and the next wave of the chain
 constexpr int kChunks = kBwd1Waves * kChunkStride;      // chunks per block = phases per tile
@@ -877,6 +880,18 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     MKB_TRACE_T(tr_t0);
     MKB_TRACE_ONLY(unsigned long long tr_hand = 0, tr_setup = 0, tr_items = 0, tr_dense = 0, tr_pro = 0, tr_p2 = 0, tr_p2rows = 0, tr_p2slots = 0, tr_p2batch = 0; const unsigned long long tr_c0 = __builtin_readcyclecounter();)
 
+    // The wave's first row tile: its 8 query-row slices are requested at ENTRY, ahead of the pool ids and the candidate-row images
+    // below (two dependent round trips) and the barrier behind them -- round 6: they used to be requested behind that barrier, a
+    // third round trip in series in a workgroup that owns its CU alone (nothing else hides it).  MKB_BWD1_Q_EARLY=0: A/B builds.
+    const int row_tiles = (A.B + TI - 1) / TI;
+    float q0[TI][KPT], q1[TI][KPT];
+    if constexpr (MKB_BWD1_Q_EARLY != 0) {
+        const int i00 = ((rg * A.tiles_per_wave) * NW + wave) * TI;
+        if (i00 < A.B) {
+#pragma unroll
+            for (int r = 0; r < TI; ++r) load_units_raw<CP, KPT>(A.Q + (int64_t)min(i00 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+        }
+    }
     for (int e = tid * 4; e < acc_slots * NC * 64; e += WG * 4)
         *reinterpret_cast<float4 *>(reinterpret_cast<float *>(s_dx) + e) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < halves) s_used[tid] = 0ull;
@@ -916,17 +931,18 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
     MKB_TRACE_T(tr_t1);
 
     const float modulus = (MODEL == MKB_PROTATE) ? A.modulus[0] : 0.f;
-    const int row_tiles = (A.B + TI - 1) / TI;
     for (int t = 0; t < A.tiles_per_wave; ++t) {
         const int tile = (rg * A.tiles_per_wave + t) * NW + wave;
         const bool have = tile < row_tiles;  // (wave-uniform; a wave without a tile only keeps the barriers)
         const int i0 = tile * TI;
-        float q0[TI][KPT], q1[TI][KPT], dq0[TI][KPT], dq1[TI][KPT];
+        float dq0[TI][KPT], dq1[TI][KPT];
+        if (MKB_BWD1_Q_EARLY == 0 || t > 0) {  // (tile 0's rows were requested at entry)
 #pragma unroll
-        for (int r = 0; r < TI; ++r) {
-            // (all eight rows' loads first, the selects behind them: a select next to its load makes the wave wait there, and the
-            // eight round trips ran one after the other)
-            if (have) load_units_raw<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+            for (int r = 0; r < TI; ++r) {
+                // (all eight rows' loads first, the selects behind them: a select next to its load makes the wave wait there, and the
+                // eight round trips ran one after the other)
+                if (have) load_units_raw<CP, KPT>(A.Q + (int64_t)min(i0 + r, A.B - 1) * A.De, A.d, NU, u0, q0[r], q1[r]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < TI; ++r) {
@@ -1482,7 +1498,9 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
 #pragma unroll
         for (int v = 0; v < KPT; ++v) { nx0[v] = 0.f; nx1[v] = 0.f; }
         // the deal goes back and forth (ranks w, 31 - w, 32 + w, ...): the rows per slot fall with the rank, so the wave with
-        // the heaviest slot of one round gets the lightest of the next
+        // the heaviest slot of one round gets the lightest of the next.  (Round 6 tried a DYNAMIC deal -- one LDS counter, the
+        // next rank claimed a slot ahead -- against the slowest wave's 21.5 k cycles here (mean 9.5 k, head-batch): slower,
+        // 93.7 / 87.0 us against 91.5 / 85.7 (head / tail, steady state, two repetitions in one call).  Removed.)
         auto rank_of = [&](int k) { return k * NW + ((k & 1) ? NW - 1 - wave : wave); };
         request(rank_of(0));
         for (int k = 0, r = rank_of(0); k * NW < n_used; ++k, r = rank_of(k)) {

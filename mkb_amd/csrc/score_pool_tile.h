@@ -25,6 +25,9 @@ namespace mkb {
 #ifndef MKB_TILE_KC
 #define MKB_TILE_KC 16
 #endif
+#ifndef MKB_TILE_CP_PIPE
+#define MKB_TILE_CP_PIPE 1  // the complex-modulus loop requests the next group's operands before it evaluates the current one, like the real-valued one (round 6 A/B, two repetitions in one call: 56.1 / 55.8 -> 55.2 / 55.3 us under the bench events; 0 = the plain loop)
+#endif
 constexpr int kTileKC = MKB_TILE_KC;            // dims per LDS chunk (a multiple of 16: every staging thread moves kTileKC / 16 quads of dims)
 constexpr int kTileNQ = kTileKC / 16;
 // (the k-pair loop below stays rolled: unrolled 2 or 4 times it is no faster -- 57.7 vs 57.0 us in round 4's A/B --, 8 times 83 us)
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void pool_fwd_tile_kernel(PoolArgs A, TileArgs
     for (int k0 = k_lo; k0 < k_hi; k0 += kTileKC) {
         const bool more = k0 + kTileKC < k_hi;
         if (more) gload(k0 + kTileKC);  // the next chunk's global loads fly under this chunk's pair math
-        if constexpr (CP) {
+        if constexpr (CP && MKB_TILE_CP_PIPE == 0) {
 #pragma unroll 1
             for (int kp = 0; kp < kTileKC / 2; ++kp) {
                 float4 q[4], x[4];
