@@ -144,6 +144,16 @@ def run_step(ctx, i):
         ctx["opt"].zero_grad()
         return loss
     lo = ((i * world + rank) * Bl) % (n - Bl)
+    if os.environ.get("MKB_BENCH_FIXED_BATCH"):  # diagnostic: the SAME rows and the SAME negatives every step (two modes: two batches)
+        lo = (i % 2) * Bl
+        sample, weight = ctx["train"][lo: lo + Bl], ctx["weights"][lo: lo + Bl]
+        fixed = ctx.setdefault("_fixed_neg", {})
+        if mode not in fixed:
+            fixed[mode] = ctx["sampler"].generate(sample, mode)
+        loss = ctx["step"](sample, weight, fixed[mode], mode)
+        ctx["opt"].step()
+        ctx["opt"].zero_grad()
+        return loss
     sample = ctx["train"][lo: lo + Bl]
     weight = ctx["weights"][lo: lo + Bl]
     ex = ctx["exchange"]
@@ -414,6 +424,13 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
     globals().update(CONFIGS[config])
     if os.environ.get("MKB_BENCH_LR"):  # diagnostic (e.g. 0: the tables never move): not a benchmark setting
         globals()["LR"] = float(os.environ["MKB_BENCH_LR"])
+    if os.environ.get("MKB_BENCH_PREWARM_OTHER"):  # diagnostic: that many steps on ANOTHER model instance (kept alive: other memory) first
+        other = build(device, rank, world, parallelism=parallelism, force=force)
+        for i in range(int(os.environ["MKB_BENCH_PREWARM_OTHER"])):
+            run_step(other, i)
+        other["opt"].flush()
+        torch.cuda.synchronize()
+        globals()["_PREWARM_KEEP"] = other
     ctx = build(device, rank, world, parallelism=parallelism, force=force)
     ctx["rows_per_rank"] = B if (args.scaling == "weak" or world == 1) else max(8, B // world)
     if world > 1 and not ctx["dims"] and not ctx["trows"]:
@@ -486,6 +503,7 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
     # are reported (windows_ms).  Per window: the host's enqueue time, the device's own time between two events on the step's
     # stream, and the largest gap between two consecutive step submissions -- enough to tell a host stall from a device stall.
     wins = []
+    sclk = torch.zeros(windows, device=device) if os.environ.get("MKB_BENCH_SCLK") else None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for w in range(windows):
         barrier()
@@ -501,6 +519,8 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         ctx["opt"].flush()  # pending zero-gradient Adam steps of rows not touched lately are part of the timed work (no-op if dense)
         t_host = time.perf_counter() - t0  # host enqueue time of the timed steps (the device may still be running)
         ev1.record()
+        if sclk is not None:  # the shader clock right behind the window's last kernel (one wave, ~20 us: outside the host's enqueue time)
+            _hip.check(_hip.lib().mkb_debug_sclk_mhz(_hip.ptr(sclk[w: w + 1]), _hip.stream_ptr()), "mkb_debug_sclk_mhz")
         barrier()
         dt = time.perf_counter() - t0
         t1 = t0 + dt
@@ -511,6 +531,8 @@ def measure(args, device, rank, world, config, parallelism, steps, warmup, profi
         wins.append({"ms": dt * 1e3, "host_enqueue_ms": t_host * 1e3, "device_ms": ev0.elapsed_time(ev1),
                      "largest_submit_gap_ms": gap * 1e3, "largest_submit_gap_at_step": gap_at,
                      "gc_ms": sum(e["ms"] for e in gc_log if t0 <= e["at"] <= t1)})
+        if sclk is not None:
+            wins[-1]["sclk_mhz_after"] = float(sclk[w].item())
     gc.callbacks.remove(gc_cb)
     order_ = sorted(range(windows), key=lambda j: wins[j]["ms"])
     med = wins[order_[(windows - 1) // 2]]  # (lower median for an even count: an actual window, not a mean of two)

@@ -402,6 +402,8 @@ int mkb_rank_scores(const mkb_tables_t *tb, const int64_t *sample, int64_t B, in
 #define MKB_PROF_POOL_BWD_X 7
 #define MKB_PROF_KINDS 8
 int mkb_profile_enable(int kernel, int on);
+/* measurement aid: the shader clock in MHz as one wave sees it over ~20 us (s_memtime cycles per 100 MHz s_memrealtime tick) */
+int mkb_debug_sclk_mhz(float *out_mhz_device, void *stream);
 int mkb_profile_read(int kernel, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

@@ -131,6 +131,7 @@ _SIGNATURES = {
                                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "mkb_check_ids": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "mkb_kl_divergence": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mkb_debug_sclk_mhz": (c_int, [c_void_p, c_void_p]),
     "mkb_rank_workspace_bytes": (c_int64, [POINTER(Tables), c_int64]),
     "mkb_rank": (c_int, [POINTER(Tables), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                          c_void_p]),

@@ -101,5 +101,24 @@ extern "C" int mkb_check_ids(const int64_t *sample, int64_t B, const int64_t *ca
     return MKB_OK;
 }
 
+// ---- measurement aids -------------------------------------------------------------------------------------------
+// shader clock right now: shader-clock cycles (s_memtime) per tick of the constant 100 MHz counter (s_memrealtime) over a short spin
+namespace mkb {
+__global__ void sclk_kernel(float *out_mhz, int spin_ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)spin_ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) *out_mhz = (float)((double)(c1 - c0) / (double)(r1 - r0) * 100.0);
+}
+}  // namespace mkb
+
+extern "C" int mkb_debug_sclk_mhz(float *out_mhz_device, void *stream) {
+    MKB_REQUIRE(out_mhz_device != nullptr, "null pointer");
+    hipLaunchKernelGGL(mkb::sclk_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_mhz_device, 2000);  // ~20 us
+    MKB_LAUNCH_CHECK();
+    return MKB_OK;
+}
+
 extern "C" int mkb_abi_version(void) { return MKB_ABI_VERSION; }
 extern "C" const char *mkb_last_error(void) { return mkb::g_err; }

@@ -22,6 +22,16 @@ cp $(ls $O/ktrace/*kernel_stats.csv 2>/dev/null | head -1) $O/rocprofv3_kernel_s
 python tools/pmc_summary.py $(find $O/pmc_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_WRITE_SIZE -name "*.db" | head -1) > $O/pmc_hbm_traffic.txt
 python tools/pmc_summary.py $(find $O/pmc_sq -name "*.db" | head -1) $(find $O/pmc_clk -name "*.db" | head -1) > $O/pmc_sq.txt 2>&1
 timeout 900 python bench.py --breakdown > $O/bench_default.json 2> $O/bench_default.err
+# the driver's protocol, three fresh processes
+for i in 1 2 3; do timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O/bench_driver_protocol.jsonl; done
+# which launch of the step gets faster over the first ~150 steps of a process (the trend inside windows_ms)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace -d $O/kt_trend -o run -- python $R/bench.py --steps 20 --warmup 5 --windows 12 --mrr-epochs 0 --no-cpu-baseline --no-traffic --no-variants --profile-kernel none > /dev/null 2> $O/kt_trend.log
+cd $R
+{ echo "# mean duration (us) of every kernel of the headline step by launch order, 20 launches per column (rocprofv3 --kernel-trace of"
+  echo "# bench.py --steps 20 --warmup 5 --windows 12): the pair kernels reach their steady duration after ~80 launches"
+  python tools/warmup_trend.py $(find $O/kt_trend -name "*.db" | head -1) 20; } > $O/warmup_trend.txt
+rm -rf $O/kt_trend
 for c in wn18rr-rotate fb15k237-complex fb15k237-transe fb15k237-distmult yago310-rotate umls-transe; do
   timeout 300 python bench.py --config $c --no-cpu-baseline --mrr-epochs 0 --no-traffic 2>/dev/null | tail -1 >> $O/bench_configs.jsonl
 done
