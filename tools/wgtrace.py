@@ -22,8 +22,8 @@ def build():
     hb.build(force=True, verbose=False, extra_flags=["-DMKB_TRACE_WG"], out=VDIR / "lib_trace.so", objdir=VDIR / "obj_trace")
 
 
-def run(kind="bwd_x", step=10):
-    step = int(step)
+def run(kind="bwd_x", step=10, n_traced=30):
+    step, n_traced = int(step), int(n_traced)
     kind_id = {"fwd": 0, "bwd_q": 1, "bwd_x": 2, "all": 3, "bwd1": 4}[kind]
     os.environ["MKB_HIP_LIB"] = str(VDIR / "lib_trace.so")
     import numpy as np
@@ -41,7 +41,7 @@ def run(kind="bwd_x", step=10):
     lib.mkb_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.mkb_debug_set_trace.restype = None
     lib.mkb_debug_set_trace(buf.data_ptr(), kind_id)
-    for i in range(30):  # steady state (the host runs ahead of the device); the last step's records win
+    for i in range(n_traced):  # steady state (the host runs ahead of the device); the last step's records win
         bench.run_step(ctx, step + 2 * i)
     torch.cuda.synchronize()
     lib.mkb_debug_set_trace(None, kind_id)
@@ -125,4 +125,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
     else:
-        run(*sys.argv[2:4])
+        run(*sys.argv[2:5])
