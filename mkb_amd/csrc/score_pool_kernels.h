@@ -1500,7 +1500,11 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         // the deal goes back and forth (ranks w, 31 - w, 32 + w, ...): the rows per slot fall with the rank, so the wave with
         // the heaviest slot of one round gets the lightest of the next.  (Round 6 tried a DYNAMIC deal -- one LDS counter, the
         // next rank claimed a slot ahead -- against the slowest wave's 21.5 k cycles here (mean 9.5 k, head-batch): slower,
-        // 93.7 / 87.0 us against 91.5 / 85.7 (head / tail, steady state, two repetitions in one call).  Removed.)
+        // 93.7 / 87.0 us against 91.5 / 85.7 (head / tail, steady state, two repetitions in one call).  Removed.
+        // Also tried and removed in round 6: keeping the dx products of the fringe's row-major half (they are evaluated there
+        // anyway, rows in registers) and adding them to LDS accumulators with ds_add_f32 -- no second half at all, every parity
+        // test green, and 133 / 95.6 us against 91.6 / 85.7: a wave's ds_add_f32 costs thousands of cycles here, not the 128
+        // the dense experiment of round 2 suggested.  profiles/r06_ab_experiments.txt)
         auto rank_of = [&](int k) { return k * NW + ((k & 1) ? NW - 1 - wave : wave); };
         request(rank_of(0));
         for (int k = 0, r = rank_of(0); k * NW < n_used; ++k, r = rank_of(k)) {
