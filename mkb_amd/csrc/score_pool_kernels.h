@@ -906,17 +906,29 @@ __global__ __launch_bounds__(kBwd1Waves * 64) void pool_bwd1_kernel(PoolArgs A) 
         const int cph0 = kChunks / halves, lc0 = __builtin_ctz((unsigned)cph0), nd0 = A.dense_lanes >> lc0;
         const int h0 = wave >> lc0, l0 = wave & (cph0 - 1);
         for (int k = 0; k < nd0; k += 4) {
+            // (round 6, from the ISA: written as "four load_units, then four stores" this was compiled into four SERIAL
+            // (scalar id load -> wait -> row loads -> wait -> LDS store) sequences -- the select inside load_units wants the data at
+            // once and the scheduler does not move loads across a wait -- eight dependent round trips in a prologue nothing hides.
+            // The four ids first, then the four rows' raw loads, a scheduling fence, the masking at the store.)
             float xa[4][KPT], xb[4][KPT];
+            int64_t idc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int j0 = l0 + (min(k + c, nd0 - 1) << lc0);
-                load_units<CP, KPT>(A.ent + A.pool[pb + A.q_slices * (j0 * halves + h0)] * A.De, A.d, CP ? A.d : (int)A.De,
-                                    (s * 64 + lane) * KPT, xa[c], xb[c]);
+                idc[c] = A.pool[pb + A.q_slices * (j0 * halves + h0)];
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                load_units_raw<CP, KPT>(A.ent + idc[c] * A.De, A.d, NU, u0, xa[c], xb[c]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (k + c >= nd0) break;
                 const int j0 = l0 + ((k + c) << lc0);
+                if (u0 >= NU) {  // (lanes past the row's end hold unit 0's data: the images carry zeros there)
+#pragma unroll
+                    for (int v = 0; v < KPT; ++v) { xa[c][v] = 0.f; xb[c][v] = 0.f; }
+                }
                 acc_t v;
                 if constexpr (NC == 1) v = xa[c][0];
                 else if constexpr (NC == 2 && !CP) { v.x = xa[c][0]; v.y = xa[c][1]; }
