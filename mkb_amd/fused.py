@@ -19,10 +19,12 @@ _workspaces = {}
 
 
 def _workspace(model, B, K, slot=0):
-    """Device scratch for the pooled kernels, cached per (device, table shape, B, K, slot); ``slot`` separates the
-    micro-batches of one step, whose forward scratch must survive until their backward half runs."""
+    """Device scratch for the pooled kernels, cached per (device, STREAM, table shape, B, K, slot); ``slot`` separates the
+    micro-batches of one step, whose forward scratch must survive until their backward half runs.  Per stream: launches on one
+    stream use the scratch one after the other, two models of one shape stepped on two streams (the in-process ranks of
+    tests/test_gpu_rows_loopback.py; a user training two models side by side) must not share it -- until round 6 they did."""
     dev = model.entity_embedding.device
-    key = (dev, model.name, model.entity_dim, model.n_entity, model.n_relation, B, K, slot)  # (the size depends on all of them)
+    key = (dev, _hip.stream_ptr(dev).value, model.name, model.entity_dim, model.n_entity, model.n_relation, B, K, slot)  # (the size depends on the last six)
     ws = _workspaces.get(key)
     if ws is None:
         n = _hip.lib().mkb_pool_step_workspace_bytes(model._tables(), B, K)
@@ -54,7 +56,7 @@ def check_workspace_guards():
     for key, g in _guards.items():
         if not bool((g == _GUARD_VALUE).all().item()):
             bad = int((g != _GUARD_VALUE).nonzero()[0].item())
-            raise RuntimeError(f"pooled-kernel workspace overrun: byte {bad} behind the workspace of {key[1:]} was overwritten")
+            raise RuntimeError(f"pooled-kernel workspace overrun: byte {bad} behind the workspace of {key[2:]} was overwritten")
 
 
 def pooled_supported(model, B, K):

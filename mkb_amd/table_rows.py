@@ -69,6 +69,25 @@ class RowsComm:
 
     SLOTS = 4
 
+    @classmethod
+    def loopback(cls, hub, rank, world, device, max_requests):
+        """A communicator over the library's IN-PROCESS transport (``mkb_rows_loop_hub_create``): every rank is a host thread of
+        this process with its own streams on ``device``.  RCCL refuses two ranks on one device; this is how the step's glue is
+        driven for world > 1 on a one-GPU box (tests/test_gpu_rows_loopback.py)."""
+        import ctypes
+
+        self = cls.__new__(cls)
+        self.world, self.rank, self.device, self.max_requests = int(world), int(rank), device, int(max_requests)
+        handle = ctypes.c_void_p()
+        with _hip.on_device(device):
+            _hip.check(_hip.lib().mkb_rows_comm_create_loopback(hub, self.rank, self.max_requests, ctypes.byref(handle)),
+                       "mkb_rows_comm_create_loopback")
+        self._handle = handle
+        self.side = torch.cuda.Stream(device=device)
+        self._n = 0
+        self._I64 = ctypes.c_int64 * self.world
+        return self
+
     def __init__(self, group, device, max_requests):
         import ctypes
 
@@ -245,9 +264,10 @@ class RowShardedTable:
     """``data`` = the rows this rank owns of a ``[n_rows, dim]`` table: global row e lives on rank ``e % world`` at shard
     index ``e // world``.  ``grad`` is the matching shard of the dense gradient (allocated on first use)."""
 
-    def __init__(self, n_rows, data, group=None, ops=None):
+    def __init__(self, n_rows, data, group=None, ops=None, rank=None, world=None):
         self.n_rows, self.group = int(n_rows), group
-        self.rank, self.world = _rank(group), _world(group)
+        # (rank / world given explicitly: ranks that are not torch.distributed processes -- the in-process transport of the tests)
+        self.rank, self.world = (_rank(group), _world(group)) if world is None else (int(rank), int(world))
         self.data = data if isinstance(data, torch.nn.Parameter) else torch.nn.Parameter(data)
         self.ops = HipRowOps() if ops is None else ops
         want = (self.n_rows - self.rank + self.world - 1) // self.world
@@ -255,10 +275,11 @@ class RowShardedTable:
             raise ValueError(f"rank {self.rank} owns {want} of {self.n_rows} rows, got a shard of {self.data.shape[0]}")
 
     @classmethod
-    def from_full(cls, full, group=None, device=None, ops=None):
-        rank, world = _rank(group), _world(group)
+    def from_full(cls, full, group=None, device=None, ops=None, rank=None, world=None):
+        if world is None:
+            rank, world = _rank(group), _world(group)
         shard = full.detach()[rank::world].clone()
-        return cls(full.shape[0], shard if device is None else shard.to(device), group, ops)
+        return cls(full.shape[0], shard if device is None else shard.to(device), group, ops, rank=rank, world=world)
 
     @property
     def dim(self):
@@ -410,10 +431,10 @@ class _Route:
                                       group=self.table.group, async_op=async_op)
 
 
-def shard_table_rows(model, group=None, device=None, ops=None):
+def shard_table_rows(model, group=None, device=None, ops=None, rank=None, world=None):
     """-> (entity ``RowShardedTable``, replicated relation ``Parameter``) from a full ``mkb_amd`` (or oracle-style) model
     that every rank built identically (same seed)."""
-    table = RowShardedTable.from_full(model.entity_embedding, group, device, ops)
+    table = RowShardedTable.from_full(model.entity_embedding, group, device, ops, rank=rank, world=world)
     rel = model.relation_embedding.detach().clone()
     return table, torch.nn.Parameter(rel if device is None else rel.to(device))
 
@@ -446,14 +467,14 @@ class TableRowShardedStep:
     position p."""
 
     def __init__(self, table, relation, alpha, model_cls=None, hidden_dim=None, gamma=None, group=None, compute=None,
-                 modulus=None):
+                 modulus=None, comm=None):
         self.table, self.relation, self.alpha, self.group = table, relation, float(alpha), group
         self.world, self.ops = table.world, table.ops
         self.compute = compute
         self._model_cls, self._hidden, self._gamma, self._modulus = model_cls, hidden_dim, gamma, modulus
         self._bufs, self._models, self._plans = {}, {}, []
         self._occ = None
-        self._comm, self._plan_bufs = None, {}
+        self._comm, self._plan_bufs = comm, {}  # (comm: a ready ``RowsComm``, e.g. ``RowsComm.loopback``; default: made at the first plan)
         self._trains_modulus = getattr(model_cls, "__name__", "") == "pRotatE"
         if compute is None and self._trains_modulus and modulus is None:
             raise ValueError("pRotatE trains its modulus: pass the replicated `modulus` Parameter to the step")

@@ -236,3 +236,115 @@ def test_disagreeing_split_sizes_and_missing_peers_are_errors_not_hangs(monkeypa
     assert not th.is_alive()
     assert "split sizes disagree" in out.get("r0", "") or "split sizes disagree" in out.get("r1", ""), out
     torch.cuda.synchronize()
+
+
+def _train_single(name, hidden, K, ds, train, batches, adam_kw):
+    from mkb_amd import models, optim, sampling
+    from mkb_amd.fused import FusedTrainStep
+
+    torch.manual_seed(5)
+    model = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=6.0).cuda()
+    ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=3)
+    opt = optim.Adam([model.entity_embedding, model.relation_embedding], lr=2e-3, **adam_kw)
+    step = FusedTrainStep(model, 0.5)
+    losses = []
+    for s, w, mode in batches:
+        losses.append(step(s, w, ns.generate(s, mode), mode).item())
+        opt.step()
+        opt.zero_grad()
+    opt.flush()
+    return losses, model.entity_embedding.detach().clone(), model.relation_embedding.detach().clone()
+
+
+@pytest.mark.parametrize("name,hidden,world,size", [("RotatE", 40, 2, "big"), ("TransE", 32, 4, "big"), ("RotatE", 24, 3, "small")])
+def test_row_sharded_training_with_library_issued_collectives_for_several_ranks(name, hidden, world, size, monkeypatch):
+    """The product's own glue (mkb_amd.table_rows.TableRowShardedStep + RowsComm) with the LIBRARY-issued collectives at world > 1:
+    every rank a host thread with its own stream, RowsComm.loopback over one hub.  Until round 6 this combination had never run:
+    gloo processes cover world > 1 with the torch.distributed form, RCCL at world 1 covers the library-issued form on one rank.
+    Five steps (plans one and two batches ahead, the sampler riding the shard's optimizer launch on odd steps, row-lazy Adam
+    with the deferred step on the FB15k-237 shards), then losses and reassembled tables against the single-device run --
+    tests/tr_worker.py's comparison and tolerances."""
+    from mkb_amd import _hip, datasets, models, optim, sampling
+    from mkb_amd.table_rows import RowsComm, TableRowShardedStep, shard_table_rows
+
+    monkeypatch.setenv("MKB_ROWS_LOOP_TIMEOUT_S", "60")
+    big = size == "big"
+    ds = (datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
+    K, Bl = 16, (64 if big else 24)
+    B = Bl * world
+    adam_kw = dict(lazy_rows=True, defer_step=True) if big else {}
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for i in range(5):
+        idx = torch.randint(len(train), (B,), generator=g).cuda()
+        batches.append((train[idx], (torch.rand(B, generator=g) + 0.1).cuda(), "head-batch" if i % 2 == 0 else "tail-batch"))
+    l0, e0, r0 = _train_single(name, hidden, K, ds, train, batches, adam_kw)
+
+    lib = _hip.lib()
+    hub = ctypes.c_void_p()
+    _hip.check(lib.mkb_rows_loop_hub_create(world, ctypes.byref(hub)), "mkb_rows_loop_hub_create")
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for r in range(world):  # (models are built one after the other on the main thread: the global CPU generator seeds them)
+        torch.manual_seed(5)
+        full = getattr(models, name)(hidden_dim=hidden, entities=ds.entities, relations=ds.relations, gamma=6.0)
+        table, rel = shard_table_rows(full, device="cuda", rank=r, world=world)
+        comm = RowsComm.loopback(hub, r, world, dev, 2 * Bl)
+        step = TableRowShardedStep(table, rel, 0.5, model_cls=getattr(models, name), hidden_dim=hidden, gamma=6.0, comm=comm)
+        opt = optim.Adam([table.data, rel], lr=2e-3, **adam_kw)
+        ns = sampling.NegativeSampling(size=K, train_triples=ds.train, entities=ds.entities, relations=ds.relations, seed=3)
+        ranks.append(dict(rank=r, table=table, rel=rel, comm=comm, step=step, opt=opt, ns=ns, losses=[]))
+    torch.cuda.synchronize()
+    errors, barrier = [], threading.Barrier(world)
+
+    def work(R):
+        try:
+            torch.cuda.set_device(0)
+            r = R["rank"]
+            todo = [(s[r * Bl: (r + 1) * Bl].contiguous(), w[r * Bl: (r + 1) * Bl].contiguous(), mode) for s, w, mode in batches]
+            barrier.wait()
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                for i, (sl, wl, mode) in enumerate(todo):
+                    nxt = todo[i + 1][0] if i + 1 < len(todo) and i != 2 else None   # planned one batch ahead (and once not)
+                    if i == 0:
+                        nxt = [todo[1][0], todo[2][0]]                               # ... and once two batches ahead
+                    if big and i % 2 == 1:  # the sampler riding the shard's optimizer launch (identical negatives)
+                        R["losses"].append(R["step"].sampled(sl, wl, R["ns"], mode, next_sample=nxt).item())
+                    else:
+                        neg = R["ns"].generate(sl, mode)
+                        R["losses"].append(R["step"](sl, wl, neg, mode, next_sample=nxt).item())
+                    R["opt"].step()
+                    R["opt"].zero_grad()
+                R["opt"].flush()
+                R["step"].check()
+            torch.cuda.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((R["rank"], repr(e), traceback.format_exc()[-1500:]))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(R,)) for R in ranks]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not any(th.is_alive() for th in threads), f"hang; errors so far: {errors}"
+    assert not errors, errors
+    full_e = torch.empty_like(e0)
+    for R in ranks:
+        full_e[R["rank"]:: world] = R["table"].data.detach()
+        st = R["comm"].stats()
+        assert st["plans"] == 5, st
+    for R in ranks:  # every rank reports the GLOBAL loss, and holds the same replicated relation table
+        np.testing.assert_allclose(R["losses"], l0, rtol=0, atol=3e-5)
+        np.testing.assert_allclose(R["rel"].detach().cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
+    d = (full_e - e0).abs()
+    assert float(d.max()) <= 3e-5, float(d.max())
+    for R in ranks:
+        R["comm"].close()
+    lib.mkb_rows_loop_hub_destroy(hub)
