@@ -256,22 +256,29 @@ def _train_single(name, hidden, K, ds, train, batches, adam_kw):
     return losses, model.entity_embedding.detach().clone(), model.relation_embedding.detach().clone()
 
 
-@pytest.mark.parametrize("name,hidden,world,size", [("RotatE", 40, 2, "big"), ("TransE", 32, 4, "big"), ("RotatE", 24, 3, "small")])
+@pytest.mark.parametrize("name,hidden,world,size", [("RotatE", 40, 2, "big"), ("TransE", 32, 4, "big"), ("RotatE", 24, 3, "small"),
+                                                    ("RotatE", 500, 8, "yago")])  # BASELINE configs[4] at its real shape: 8 ranks x 1024 rows, K 256
 def test_row_sharded_training_with_library_issued_collectives_for_several_ranks(name, hidden, world, size, monkeypatch):
     """The product's own glue (mkb_amd.table_rows.TableRowShardedStep + RowsComm) with the LIBRARY-issued collectives at world > 1:
     every rank a host thread with its own stream, RowsComm.loopback over one hub.  Until round 6 this combination had never run:
     gloo processes cover world > 1 with the torch.distributed form, RCCL at world 1 covers the library-issued form on one rank.
     Five steps (plans one and two batches ahead, the sampler riding the shard's optimizer launch on odd steps, row-lazy Adam
     with the deferred step on the FB15k-237 shards), then losses and reassembled tables against the single-device run --
-    tests/tr_worker.py's comparison and tolerances."""
+    tests/tr_worker.py's comparison and tolerances.  "yago": datasets.Yago310 (123,182 entities; synthetic training triples) + RotatE
+    hidden 500, K = 256, 1024 rows per rank on EIGHT ranks -- the configuration north_star shards, at full size."""
+    import warnings
+
     from mkb_amd import _hip, datasets, models, optim, sampling
     from mkb_amd.table_rows import RowsComm, TableRowShardedStep, shard_table_rows
 
-    monkeypatch.setenv("MKB_ROWS_LOOP_TIMEOUT_S", "60")
-    big = size == "big"
-    ds = (datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
+    monkeypatch.setenv("MKB_ROWS_LOOP_TIMEOUT_S", "120")
+    yago = size == "yago"
+    big = size == "big" or yago
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        ds = (datasets.Yago310 if yago else datasets.Fb15k237 if big else datasets.Umls)(batch_size=64, shuffle=False, seed=42, num_workers=0)
     train = torch.as_tensor(np.asarray(ds.train, dtype=np.int64)).cuda()
-    K, Bl = 16, (64 if big else 24)
+    K, Bl = (256, 1024) if yago else (16, 64 if big else 24)
     B = Bl * world
     adam_kw = dict(lazy_rows=True, defer_step=True) if big else {}
     g = torch.Generator().manual_seed(9)
@@ -342,9 +349,12 @@ def test_row_sharded_training_with_library_issued_collectives_for_several_ranks(
         assert st["plans"] == 5, st
     for R in ranks:  # every rank reports the GLOBAL loss, and holds the same replicated relation table
         np.testing.assert_allclose(R["losses"], l0, rtol=0, atol=3e-5)
-        np.testing.assert_allclose(R["rel"].detach().cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-5)
+        np.testing.assert_allclose(R["rel"].detach().cpu().numpy(), r0.cpu().numpy(), rtol=0, atol=3e-4 if yago else 3e-5)
+    # (Adam's update is scale-free: where a gradient element is ~0 the order of the fp32 atomics decides a step of up to lr; at
+    # YAGO3-10's size a handful of the 123 M elements land a few 1e-5 apart -- tests/tr_worker.py: 3e-4 there, the bulk within 3e-5)
     d = (full_e - e0).abs()
-    assert float(d.max()) <= 3e-5, float(d.max())
+    assert float(d.max()) <= (3e-4 if yago else 3e-5), float(d.max())
+    assert float((d > 3e-5).float().mean()) <= 1e-6, float((d > 3e-5).float().mean())
     for R in ranks:
         R["comm"].close()
     lib.mkb_rows_loop_hub_destroy(hub)
