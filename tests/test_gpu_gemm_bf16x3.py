@@ -162,7 +162,7 @@ def test_workspace_guard_notices_a_write_behind_the_workspace(monkeypatch):
     m = models.DistMult(hidden_dim=44, entities=ds.entities, relations=ds.relations, gamma=6).cuda()
     ws = fused._workspace(m, 96, 24)  # (a shape no other test uses: a fresh cache entry, with its guard)
     fused.check_workspace_guards()
-    key = [k for k in fused._guards if k[5:7] == (96, 24) and k[2] == m.entity_dim][0]
+    key = [k for k in fused._guards if k[6:8] == (96, 24) and k[3] == m.entity_dim][0]  # (device, stream, name, entity_dim, n_entity, n_relation, B, K, slot)
     guard = fused._guards[key]
     assert guard.data_ptr() == ws.data_ptr() + ws.numel()
     guard[5] = 0
