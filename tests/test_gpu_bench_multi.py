@@ -106,3 +106,22 @@ def test_bench_safety_line_of_the_row_sharded_step(timeout):
         assert "did not finish in time" in d["error"] and d["steps"] == 40
     else:
         assert "error" not in d and d["torch_distributed_form"]["value"] > 0 and d["steps"] == 4
+
+
+def test_bench_line_reports_the_median_window_and_every_window():
+    """Round 6: the timed region is R back-to-back windows of --steps steps; ms_per_step / value are the MEDIAN window (an actual
+    window: the lower median for an even count) and nothing is dropped: every window is listed with its instruments."""
+    from conftest import ROOT
+
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--windows", "6", "--config", "wn18rr-rotate", "--no-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["windows"] == 6 and len(d["windows_ms"]) == 6 == len(d["windows_detail"])
+    per_step = sorted(w / 6 for w in d["windows_ms"])
+    assert abs(d["ms_per_step"] - per_step[2]) < 1e-6 * per_step[2] + 1e-5, (d["ms_per_step"], per_step)  # lower median of six
+    assert abs(d["value"] - 1024 * 129 / (d["ms_per_step"] / 1e3)) < 1e-3 * d["value"]                   # B * (K + 1) per step
+    for w in d["windows_detail"]:
+        assert {"ms", "host_enqueue_ms", "device_ms", "largest_submit_gap_ms", "largest_submit_gap_at_step", "gc_ms"} <= set(w)
+        assert 0 < w["host_enqueue_ms"] <= w["ms"] + 1e-3 and 0 < w["device_ms"] <= w["ms"] + 0.5
+    assert d["t_host_ms_per_step"] > 0 and isinstance(d["gc_collections_during_windows"], list)
